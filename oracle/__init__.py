@@ -1,0 +1,20 @@
+"""CPU oracle for the deadtrees U-Net hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is product code: only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it, and only as the checker / reported baseline.
+The product path (``deadtrees_amd``) never imports this package and fails
+loudly when its HIP library is missing.
+
+Pinning status:
+  * losses / one-hot / distance maps / block split-merge: pinned against the
+    reference's own importable modules (``oracle/make_golden.py`` imports
+    ``deadtrees.loss`` and ``deadtrees.utils.data_handling`` from
+    /root/reference and writes ``tests/golden/*.npz``) and against the
+    reference's known-answer test (tests/test_tiler.py:56-77).
+  * network (smp ``Unet`` + ``resnet34``): the arithmetic lives in the
+    un-vendored third-party package ``segmentation_models_pytorch>=0.2.1``
+    (reference setup.py:47) which is absent here -> PARITY UNPINNED for the
+    network topology; the oracle restates the published smp/torchvision
+    topology from torch primitives.
+"""
