@@ -1,0 +1,89 @@
+"""ctypes binding of libdeadtrees_hip.so (the C ABI declared in include/deadtrees_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  (`oracle/` is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeadtrees_hip.so")
+
+c_f = C.c_void_p  # device pointers travel as raw addresses
+I32, I64, F32, F64, SZ = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, I32) for n in (
+        "B", "Hin", "Win", "C0", "C1", "mode0", "Ho", "Wo", "Cout", "ksize", "stride", "pad",
+        "cout_split", "accumulate")]
+
+
+_P = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes).  Must list every symbol of include/deadtrees_hip.h
+# (tests/test_abi.py cross-checks this table against the header).
+SIGNATURES = {
+    "dt_last_error": (C.c_char_p, []),
+    "dt_version": (C.c_int, []),
+    "dt_device_count": (C.c_int, []),
+    "dt_conv2d_stat_rows": (C.c_int, [_P]),
+    "dt_conv2d": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "dt_weight_flip_transpose": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_conv2d_wgrad_workspace": (SZ, [_P]),
+    "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f]),
+    "dt_bn_finalize": (C.c_int, [c_f, C.c_int, C.c_int, F64, c_f, c_f, F32, F32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "dt_bn_eval_affine": (C.c_int, [c_f, c_f, c_f, c_f, F32, C.c_int, c_f, c_f, c_f]),
+    "dt_bn_act": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, C.c_int, c_f]),
+    "dt_bn_bwd_rows": (C.c_int, [I64, C.c_int]),
+    "dt_bn_bwd_reduce": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, c_f]),
+    "dt_bn_bwd_apply": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int, I64,
+                                  C.c_int, c_f]),
+    "dt_maxpool3x3s2": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_maxpool3x3s2_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_upsample2x_bwd": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_nchw_to_nhwc": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_nhwc_to_nchw": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_normalize_u8": (C.c_int, [c_f, c_f, I64, C.c_int, C.c_int, C.POINTER(F32), C.POINTER(F32), c_f]),
+    "dt_head_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_head_bwd_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dt_head_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_head_bwd_finalize": (C.c_int, [c_f, C.c_int, c_f, c_f, C.c_int, C.c_int, c_f]),
+    "dt_seg_loss_acc_doubles": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_sumsq_rows": (C.c_int, [I64]),
+    "dt_sumsq": (C.c_int, [c_f, I64, c_f, c_f]),
+    "dt_clip_coef": (C.c_int, [c_f, C.c_int, F32, F32, c_f, c_f, c_f]),
+    "dt_adam_step": (C.c_int, [c_f, c_f, c_f, c_f, I64, F32, F32, F32, F32, F32, F32, c_f, c_f, c_f]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C deadtrees_amd/csrc`).  deadtrees_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError(f"libdeadtrees_hip.so does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dt_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

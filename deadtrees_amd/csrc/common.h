@@ -1,0 +1,44 @@
+// Shared host/device helpers for libdeadtrees_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/deadtrees_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void dt_set_error(const char* fmt, ...);
+
+#define DT_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      dt_set_error(__VA_ARGS__);         \
+      return DT_EINVAL;                  \
+    }                                    \
+  } while (0)
+
+#define DT_LAUNCH_CHECK()                                                        \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      dt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return DT_EHIP;                                                            \
+    }                                                                            \
+  } while (0)
+
+static inline int dt_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// wave64 butterfly sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,384 @@
+// Direct (im2col-free) NHWC convolution on the fp32 matrix cores of gfx950.
+//
+// Replaces ATen conv2d on the reference hot path (smp.Unet(resnet34) forward reached from
+// deadtrees/network/segmodel.py:214,235,280 and deployment/inference.py:60) and, through the
+// input modes, also F.interpolate(nearest x2) + torch.cat of the smp decoder block (in-tree twin:
+// deadtrees/network/extra/resunet/decoder.py:41-43) and the data-gradient convolutions of autograd.
+//
+// Design (MI355X-first):
+//   * one workgroup (4 waves) owns a 256-pixel output tile (TH x TW) x TN output channels;
+//   * the input halo tile for CK input channels is staged ONCE in LDS (channel-planar, so the
+//     32 pixels of an MFMA row-fragment are 32 consecutive dwords: conflict-free ds_read_b32) and is
+//     re-used by all KS*KS taps — no im2col buffer ever exists in HBM;
+//   * virtual nearest-upsample / zero-insertion / channel concat are index arithmetic in the LDS fill;
+//   * the contraction over input channels runs on v_mfma_f32_32x32x2_f32: exact fp32 fma chains at
+//     the fp32 peak (157 TF) with one VGPR per operand (MI355X_MICROARCH.md §Matrix cores);
+//   * epilogue: coalesced 128-B row stores + per-channel sum / sum-of-squares partials for the
+//     following BatchNorm (wave64 shuffle -> LDS -> one row per workgroup; reduced later in fixed
+//     order, so results are run-to-run deterministic — no float atomics).
+#include "common.h"
+
+struct ConvArgs {
+  const float* src0;
+  const float* src1;
+  const float* w;
+  float* out0;
+  float* out1;
+  float* stats;
+  int B, Hin, Win, C0, C1, mode0;
+  int Ho, Wo, Cout, cout_split, pad, accumulate;
+  int tiles_x, tiles_y, n_tiles, P;
+};
+
+__host__ __device__ constexpr int plane_pad(int n, int mod8) {
+  // smallest p >= n with p % 8 == mod8
+  int p = n;
+  while ((p & 7) != mod8) ++p;
+  return p;
+}
+
+template <int KS, int STRIDE, int TW, int CK>
+struct ConvGeom {
+  static constexpr int TH = 256 / TW;
+  static constexpr int LS = (KS == 1) ? 1 : STRIDE;  // pixel step inside the LDS tile
+  static constexpr int GS = (KS == 1) ? STRIDE : 1;  // pixel step in global memory per LDS pixel
+  static constexpr int HALO_H = (TH - 1) * LS + KS;
+  static constexpr int HALO_W = (TW - 1) * LS + KS;
+  static constexpr int PMOD = (CK >= 32) ? 1 : (CK == 16 ? 2 : (CK == 8 ? 4 : 0));
+  static constexpr int PLANE = plane_pad(HALO_H * HALO_W, PMOD);
+  static constexpr int TAPS = KS * KS;
+};
+
+// Stage CK channels [c0, c0+CK) of the logical input halo tile into LDS, channel-planar.
+template <int KS, int STRIDE, int TW, int CK>
+__device__ __forceinline__ void fill_input_planar(float* __restrict__ lds_in, const ConvArgs& a, int b,
+                                                  int iy0, int ix0, int c0) {
+  using G = ConvGeom<KS, STRIDE, TW, CK>;
+  const float* src;
+  int C, cc, mode;
+  if (c0 < a.C0) {
+    src = a.src0; C = a.C0; cc = c0; mode = a.mode0;
+  } else {
+    src = a.src1; C = a.C1; cc = c0 - a.C0; mode = 0;
+  }
+  const int Hs = mode ? (a.Hin >> 1) : a.Hin;
+  const int Ws = mode ? (a.Win >> 1) : a.Win;
+  const int tid = threadIdx.x;
+  if ((C & 3) == 0 && (CK & 3) == 0) {
+    constexpr int Q = CK / 4;
+    constexpr int TOTAL = G::HALO_H * G::HALO_W * Q;
+    for (int idx = tid; idx < TOTAL; idx += 256) {
+      const int q = idx % Q;
+      const int pix = idx / Q;
+      const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
+      const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && (cc + 4 * q) < C;
+      if (mode == 2) ok = ok && (((iy | ix) & 1) == 0);
+      if (ok) {
+        const int sy = mode ? (iy >> 1) : iy, sx = mode ? (ix >> 1) : ix;
+        v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + sy) * Ws + sx) * C + cc + 4 * q);
+      }
+      float* d = lds_in + (4 * q) * G::PLANE + pix;
+      d[0] = v[0];
+      d[G::PLANE] = v[1];
+      d[2 * G::PLANE] = v[2];
+      d[3 * G::PLANE] = v[3];
+    }
+  } else {
+    constexpr int TOTAL = G::HALO_H * G::HALO_W * CK;
+    for (int idx = tid; idx < TOTAL; idx += 256) {
+      const int c = idx % CK;
+      const int pix = idx / CK;
+      const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
+      const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
+      float v = 0.f;
+      bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && (cc + c) < C;
+      if (mode == 2) ok = ok && (((iy | ix) & 1) == 0);
+      if (ok) {
+        const int sy = mode ? (iy >> 1) : iy, sx = mode ? (ix >> 1) : ix;
+        v = src[(((size_t)b * Hs + sy) * Ws + sx) * C + cc + c];
+      }
+      lds_in[c * G::PLANE + pix] = v;
+    }
+  }
+}
+
+// Stage weights [tap][c0..c0+CK)[n0..n0+TN) into LDS as [tap][CK][TN].
+template <int TAPS, int CK, int TN>
+__device__ __forceinline__ void fill_weights(float* __restrict__ lds_w, const float* __restrict__ w, int Cin,
+                                             int Cout, int c0, int n0) {
+  const int tid = threadIdx.x;
+  if ((Cout & 3) == 0) {
+    constexpr int Q = TN / 4;
+    constexpr int TOTAL = TAPS * CK * Q;
+    for (int idx = tid; idx < TOTAL; idx += 256) {
+      const int q = idx % Q;
+      const int row = idx / Q;  // tap*CK + k
+      const int tap = row / CK, k = row - tap * CK;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + k < Cin && n0 + 4 * q < Cout)
+        v = *reinterpret_cast<const f32x4*>(w + ((size_t)tap * Cin + c0 + k) * Cout + n0 + 4 * q);
+      *reinterpret_cast<f32x4*>(lds_w + row * TN + 4 * q) = v;
+    }
+  } else {
+    constexpr int TOTAL = TAPS * CK * TN;
+    for (int idx = tid; idx < TOTAL; idx += 256) {
+      const int n = idx % TN;
+      const int row = idx / TN;
+      const int tap = row / CK, k = row - tap * CK;
+      float v = 0.f;
+      if (c0 + k < Cin && n0 + n < Cout) v = w[((size_t)tap * Cin + c0 + k) * Cout + n0 + n];
+      lds_w[row * TN + n] = v;
+    }
+  }
+}
+
+template <int KS, int STRIDE, int TW, int TN, int CK>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
+  using G = ConvGeom<KS, STRIDE, TW, CK>;
+  constexpr int NT = TN / 32;
+  constexpr int IN_ELEMS = CK * G::PLANE;
+  constexpr int W_ELEMS = G::TAPS * CK * TN;
+  __shared__ __attribute__((aligned(16))) float lds[IN_ELEMS + W_ELEMS];
+  float* lds_in = lds;
+  float* lds_w = lds + IN_ELEMS;
+  static_assert((IN_ELEMS & 3) == 0, "weight region must stay 16-byte aligned");
+
+  const int wg = blockIdx.x;
+  const int nt = wg % a.n_tiles;
+  const int sp = wg / a.n_tiles;
+  const int tx = sp % a.tiles_x;
+  const int ty = (sp / a.tiles_x) % a.tiles_y;
+  const int b = sp / (a.tiles_x * a.tiles_y);
+  const int oy0 = ty * G::TH, ox0 = tx * TW, n0 = nt * TN;
+  const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane >> 5, r = lane & 31;
+
+  int abase[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int p = (wave * 2 + mt) * 32 + r;
+    const int py = p / TW, px = p % TW;
+    abase[mt] = s * G::PLANE + py * G::LS * G::HALO_W + px * G::LS;
+  }
+  const int bbase = s * TN + r;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
+
+  const int Cin = a.C0 + a.C1;
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    __syncthreads();
+    fill_input_planar<KS, STRIDE, TW, CK>(lds_in, a, b, iy0, ix0, c0);
+    fill_weights<G::TAPS, CK, TN>(lds_w, a.w, Cin, a.Cout, c0, n0);
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < G::TAPS; ++tap) {
+      const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+      for (int kk = 0; kk < CK / 2; ++kk) {
+        float av[2], bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) av[mt] = lds_in[abase[mt] + 2 * kk * G::PLANE + kh * G::HALO_W + kw];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = lds_w[bbase + (tap * CK + 2 * kk) * TN + 32 * j];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[j], acc[mt][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---------------- epilogue: store + BatchNorm partial statistics
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + 32 * j + r;
+    float* outp = a.out0;
+    int ld = a.Cout, nn = n;
+    if (a.cout_split > 0) {
+      if (n0 >= a.cout_split) {
+        outp = a.out1; ld = a.Cout - a.cout_split; nn = n - a.cout_split;
+      } else {
+        ld = a.cout_split;
+      }
+    }
+    const bool nok = n < a.Cout;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * s;
+        const int p = (wave * 2 + mt) * 32 + row;
+        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        if (nok && oy < a.Ho && ox < a.Wo) {
+          float v = acc[mt][j][i];
+          s1[j] += v;
+          s2[j] += v * v;
+          const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld + nn;
+          if (a.accumulate && outp == a.out0) v += outp[o];
+          outp[o] = v;
+        }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    __syncthreads();  // all waves done with lds_in / lds_w
+    float* red = lds;  // [2][4 waves][TN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (s == 0) {
+        red[wave * TN + 32 * j + r] = t1;
+        red[4 * TN + wave * TN + 32 * j + r] = t2;
+      }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 2 * TN) {
+      const int which = t / TN, c = t % TN;
+      if (n0 + c < a.Cout) {
+        const float* rr = red + which * 4 * TN + c;
+        const float v = (rr[0] + rr[TN]) + (rr[2 * TN] + rr[3 * TN]);
+        a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host dispatch
+struct ConvCfg {
+  int tw, tn;
+};
+
+static ConvCfg pick_cfg(const dt_conv_desc* d) {
+  ConvCfg c;
+  c.tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
+  int tn = d->Cout >= 64 ? 64 : 32;
+  if (d->cout_split > 0 && (d->cout_split % 64) != 0) tn = 32;
+  // keep >= 2 workgroups per CU in flight when the grid is small (deep layers: few spatial tiles)
+  if (tn == 64) {
+    const int th = 256 / c.tw;
+    const long wgs = (long)d->B * dt_cdiv(d->Ho, th) * dt_cdiv(d->Wo, c.tw) * dt_cdiv(d->Cout, 64);
+    if (wgs < 512) tn = 32;
+  }
+  c.tn = tn;
+  return c;
+}
+
+static int validate(const dt_conv_desc* d) {
+  DT_REQUIRE(d != nullptr, "conv: null descriptor");
+  DT_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad sizes");
+  DT_REQUIRE(d->ksize == 1 || d->ksize == 3 || d->ksize == 7, "conv: ksize %d unsupported", d->ksize);
+  DT_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride %d unsupported", d->stride);
+  DT_REQUIRE(d->mode0 >= 0 && d->mode0 <= 2, "conv: mode0 %d", d->mode0);
+  DT_REQUIRE(d->mode0 == 0 || ((d->Hin & 1) == 0 && (d->Win & 1) == 0), "conv: mode0 needs even Hin/Win");
+  const int ho = (d->Hin + 2 * d->pad - d->ksize) / d->stride + 1;
+  const int wo = (d->Win + 2 * d->pad - d->ksize) / d->stride + 1;
+  DT_REQUIRE(ho == d->Ho && wo == d->Wo, "conv: Ho/Wo (%d,%d) != expected (%d,%d)", d->Ho, d->Wo, ho, wo);
+  DT_REQUIRE(d->C1 == 0 || (d->C0 % 16) == 0, "conv: concat needs C0 %% 16 == 0");
+  DT_REQUIRE(d->cout_split == 0 || ((d->cout_split % 32) == 0 && d->cout_split < d->Cout),
+             "conv: cout_split must be a multiple of 32 below Cout");
+  DT_REQUIRE(d->ksize != 7 || (d->stride == 2 && d->C1 == 0 && d->C0 <= 4), "conv: 7x7 only as the stem");
+  return DT_OK;
+}
+
+extern "C" int dt_conv2d_stat_rows(const dt_conv_desc* d) {
+  if (validate(d) != DT_OK) return DT_EINVAL;
+  ConvCfg c = pick_cfg(d);
+  return d->B * dt_cdiv(d->Ho, 256 / c.tw) * dt_cdiv(d->Wo, c.tw);
+}
+
+template <int KS, int STRIDE, int TW, int TN, int CK>
+static int launch(const ConvArgs& a, hipStream_t st) {
+  const long grid = (long)a.P * a.n_tiles;
+  hipLaunchKernelGGL((conv_fwd_kernel<KS, STRIDE, TW, TN, CK>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+template <int KS, int STRIDE, int CK>
+static int launch_tw_tn(const ConvArgs& a, const ConvCfg& c, hipStream_t st) {
+  if (c.tn == 64) {
+    if (c.tw == 32) return launch<KS, STRIDE, 32, 64, CK>(a, st);
+    if (c.tw == 16) return launch<KS, STRIDE, 16, 64, CK>(a, st);
+    return launch<KS, STRIDE, 8, 64, CK>(a, st);
+  }
+  if (c.tw == 32) return launch<KS, STRIDE, 32, 32, CK>(a, st);
+  if (c.tw == 16) return launch<KS, STRIDE, 16, 32, CK>(a, st);
+  return launch<KS, STRIDE, 8, 32, CK>(a, st);
+}
+
+extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const float* w,
+                         float* out0, float* out1, float* stats, void* stream) {
+  int rc = validate(d);
+  if (rc != DT_OK) return rc;
+  DT_REQUIRE(src0 && w && out0, "conv: null pointer");
+  DT_REQUIRE(d->C1 == 0 || src1, "conv: src1 missing");
+  DT_REQUIRE(d->cout_split == 0 || out1, "conv: out1 missing");
+  ConvCfg c = pick_cfg(d);
+  ConvArgs a;
+  a.src0 = src0; a.src1 = src1; a.w = w; a.out0 = out0; a.out1 = out1; a.stats = stats;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.cout_split = d->cout_split; a.pad = d->pad;
+  a.accumulate = d->accumulate;
+  a.tiles_x = dt_cdiv(d->Wo, c.tw);
+  a.tiles_y = dt_cdiv(d->Ho, 256 / c.tw);
+  a.n_tiles = dt_cdiv(d->Cout, c.tn);
+  a.P = d->B * a.tiles_x * a.tiles_y;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->ksize == 3 && d->stride == 1) return launch_tw_tn<3, 1, 16>(a, c, st);
+  if (d->ksize == 3 && d->stride == 2) return launch_tw_tn<3, 2, 8>(a, c, st);
+  if (d->ksize == 1 && d->stride == 2) return launch_tw_tn<1, 2, 16>(a, c, st);
+  if (d->ksize == 1 && d->stride == 1) return launch_tw_tn<1, 1, 16>(a, c, st);
+  if (d->ksize == 7) {
+    if (c.tw == 32) return launch<7, 2, 32, 64, 4>(a, st);
+    if (c.tw == 16) return launch<7, 2, 16, 64, 4>(a, st);
+    return launch<7, 2, 8, 64, 4>(a, st);
+  }
+  dt_set_error("conv: configuration not implemented");
+  return DT_ENOSYS;
+}
+
+// ---------------------------------------------------------------- weight flip+transpose for dgrad
+__global__ void weight_flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wd, int taps,
+                                             int Cin, int Cout) {
+  // wd[tap'][co][ci] = w[taps-1-tap'][ci][co]; 32x32 LDS transpose tiles
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  const float* wsrc = w + (size_t)(taps - 1 - tap) * Cin * Cout;
+  for (int i = ty; i < 32; i += 8) {
+    const int ci = ci0 + i, co = co0 + tx;
+    tile[i][tx] = (ci < Cin && co < Cout) ? wsrc[(size_t)ci * Cout + co] : 0.f;
+  }
+  __syncthreads();
+  float* wdst = wd + (size_t)tap * Cin * Cout;
+  for (int i = ty; i < 32; i += 8) {
+    const int co = co0 + i, ci = ci0 + tx;
+    if (ci < Cin && co < Cout) wdst[(size_t)co * Cin + ci] = tile[tx][i];
+  }
+}
+
+extern "C" int dt_weight_flip_transpose(const float* w, float* wd, int ksize, int Cin, int Cout, void* stream) {
+  DT_REQUIRE(w && wd && ksize > 0 && Cin > 0 && Cout > 0, "flip_transpose: bad args");
+  dim3 grid(dt_cdiv(Cout, 32), dt_cdiv(Cin, 32), ksize * ksize);
+  hipLaunchKernelGGL(weight_flip_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wd, ksize * ksize,
+                     Cin, Cout);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

@@ -1,0 +1,483 @@
+// HBM-bound NHWC passes of the U-Net hot path: BatchNorm finalize/apply/backward, ReLU, residual add,
+// max-pool, nearest-upsample backward, layout shuttles, uint8 normalisation.
+// Replaces ATen batch_norm / relu_ / add / max_pool2d / interpolate-backward launched by the smp
+// ResNet-34 encoder + UnetDecoder (reference call site deadtrees/network/segmodel.py:214).
+// All kernels: 16 B per lane (f32x4) coalesced along the channel-fastest NHWC axis, wave64 shuffle
+// reductions, deterministic two-stage sums (no float atomics).
+#include "common.h"
+
+#include <math.h>
+
+// ------------------------------------------------------------------ BN finalize
+// one workgroup per 16 channels; 256 threads = 16 channels x 16 row-lanes
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int P, int C,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float momentum, float* running_mean,
+                                                          float* running_var, float* mean, float* invstd,
+                                                          float* scale, float* shift) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int p = rl; p < P; p += 16) {
+      s1 += (double)stats[(size_t)p * C + c];
+      s2 += (double)stats[((size_t)P + p) * C + c];
+    }
+  }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < 16; ++i) {
+      t1 += red[0][i][cl];
+      t2 += red[1][i][cl];
+    }
+    const double m = t1 / count;
+    double var = t2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    const float sc = gamma[c] * (float)is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    if (running_mean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+extern "C" int dt_bn_finalize(const float* stats, int P, int C, double count, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                              void* stream) {
+  DT_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && P > 0 && C > 0 && count > 0,
+             "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(dt_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, stats, P, C,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+
+extern "C" int dt_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                 float eps, int C, float* scale, float* shift, void* stream) {
+  DT_REQUIRE(gamma && beta && rm && rv && scale && shift && C > 0, "bn_eval_affine: bad args");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(dt_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma,
+                     beta, rm, rv, eps, C, scale, shift);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ BN apply (+residual) (+ReLU)
+__global__ __launch_bounds__(256) void bn_act_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift,
+                                                     const f32x4* __restrict__ res,
+                                                     const float* __restrict__ rscale,
+                                                     const float* __restrict__ rshift, f32x4* __restrict__ out,
+                                                     int64_t n4, int C4, int relu) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int c4 = (int)(i % C4);
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
+    f32x4 v = y[i] * sc + sh;
+    if (res) {
+      f32x4 rv = res[i];
+      if (rscale) rv = rv * reinterpret_cast<const f32x4*>(rscale)[c4] + reinterpret_cast<const f32x4*>(rshift)[c4];
+      v += rv;
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    out[i] = v;
+  }
+}
+
+static inline int ew_grid(int64_t n_items) {
+  int64_t g = (n_items + 255) / 256;
+  const int64_t cap = 256 * 16;  // 16 workgroups per CU, grid-stride beyond
+  return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+extern "C" int dt_bn_act(const float* y, const float* scale, const float* shift, const float* res,
+                         const float* rscale, const float* rshift, float* out, int64_t n_pix, int C, int relu,
+                         void* stream) {
+  DT_REQUIRE(y && scale && shift && out && n_pix > 0 && C > 0 && (C & 3) == 0, "bn_act: bad args (C%%4)");
+  DT_REQUIRE((rscale == nullptr) == (rshift == nullptr), "bn_act: rscale/rshift must come together");
+  const int64_t n4 = n_pix * C / 4;
+  hipLaunchKernelGGL(bn_act_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)y, scale,
+                     shift, (const f32x4*)res, rscale, rshift, (f32x4*)out, n4, C / 4, relu);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ BN backward
+// pass 1: per-channel partial sums of g and g*xhat.  Workgroup = 256 threads covering a block of
+// ROWS pixels; thread t owns channel-quad (t % C4 within a 256/C4 pixel stripe).
+#define BNB_PIX_PER_WG 1024
+
+extern "C" int dt_bn_bwd_rows(int64_t n_pix, int C) {
+  (void)C;
+  return dt_cdiv(n_pix, BNB_PIX_PER_WG);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout,
+                                                            const float* __restrict__ out_act,
+                                                            const float* __restrict__ y,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ red, int64_t n_pix, int C, int P) {
+  extern __shared__ float sm[];  // [2][rows_per_iter][C]  (rows_per_iter = 1024/C*... see below)
+  const int C4 = C >> 2;
+  const int t = threadIdx.x;
+  // threads are laid out as (pixel lane pl, channel quad q): q fastest for coalescing
+  const int lanes_per_pix = C4 < 256 ? C4 : 256;  // C4 <= 256 always holds for C <= 1024
+  const int pix_par = 256 / lanes_per_pix;        // pixels processed concurrently
+  const int q = t % lanes_per_pix, pl = t / lanes_per_pix;
+  const int64_t p0 = (int64_t)blockIdx.x * BNB_PIX_PER_WG;
+  int64_t p1 = p0 + BNB_PIX_PER_WG;
+  if (p1 > n_pix) p1 = n_pix;
+  for (int qq = q; qq < C4; qq += lanes_per_pix) {
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[qq];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[qq];
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t p = p0 + pl; p < p1; p += pix_par) {
+      const size_t o = (size_t)p * C4 + qq;
+      f32x4 g = reinterpret_cast<const f32x4*>(dout)[o];
+      if (out_act) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(out_act)[o];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+      }
+      const f32x4 xh = (reinterpret_cast<const f32x4*>(y)[o] - mu) * is;
+      sg += g;
+      sgx += g * xh;
+    }
+    // combine the pix_par pixel-lanes through LDS
+    float* s0 = sm;                       // [pix_par][C]
+    float* s1 = sm + (size_t)pix_par * C;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s0[(size_t)pl * C + 4 * qq + k] = sg[k];
+      s1[(size_t)pl * C + 4 * qq + k] = sgx[k];
+    }
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int i = 0; i < pix_par; ++i) {
+          a0 += s0[(size_t)i * C + 4 * qq + k];
+          a1 += s1[(size_t)i * C + 4 * qq + k];
+        }
+        red[(size_t)blockIdx.x * C + 4 * qq + k] = a0;
+        red[((size_t)P + blockIdx.x) * C + 4 * qq + k] = a1;
+      }
+    }
+  }
+}
+
+extern "C" int dt_bn_bwd_reduce(const float* dout, const float* out_act, const float* y, const float* mean,
+                                const float* invstd, float* red, int64_t n_pix, int C, void* stream) {
+  DT_REQUIRE(dout && y && mean && invstd && red && n_pix > 0 && C > 0 && (C & 3) == 0 && C <= 1024,
+             "bn_bwd_reduce: bad args");
+  const int P = dt_bn_bwd_rows(n_pix, C);
+  const int C4 = C / 4;
+  const int lanes = C4 < 256 ? C4 : 256;
+  DT_REQUIRE(256 % lanes == 0, "bn_bwd_reduce: C/4 must divide 256 (C=%d)", C);
+  const size_t smem = (size_t)2 * (256 / lanes) * C * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(P), dim3(256), smem, (hipStream_t)stream, dout, out_act, y, mean,
+                     invstd, red, n_pix, C, P);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// finalize the per-channel sums (fp64, fixed order): sums[0][C] = sum g, sums[1][C] = sum g*xhat
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restrict__ red, int P, int C,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sh[2][16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int p = rl; p < P; p += 16) {
+      s1 += (double)red[(size_t)p * C + c];
+      s2 += (double)red[((size_t)P + p) * C + c];
+    }
+  sh[0][rl][cl] = s1;
+  sh[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < 16; ++i) {
+      t1 += sh[0][i][cl];
+      t2 += sh[1][i][cl];
+    }
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const f32x4* __restrict__ dout, const f32x4* __restrict__ out_act, const f32x4* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta, f32x4* __restrict__ dy,
+    f32x4* __restrict__ dres, int dres_acc, int64_t n4, int C4, float inv_count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int c4 = (int)(i % C4);
+    f32x4 g = dout[i];
+    if (out_act) {
+      const f32x4 a = out_act[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+    }
+    if (dres) {
+      if (dres_acc)
+        dres[i] = dres[i] + g;
+      else
+        dres[i] = g;
+    }
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c4];
+    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
+    const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c4];
+    const f32x4 db = reinterpret_cast<const f32x4*>(dbeta)[c4];
+    const f32x4 xh = (y[i] - mu) * is;
+    dy[i] = ga * is * (g - db * inv_count - xh * (dg * inv_count));
+  }
+}
+
+extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
+                               const float* invstd, const float* gamma, const float* red, int P, float* dgamma,
+                               float* dbeta, float* dy, float* dres, int dres_accumulate, int64_t n_pix, int C,
+                               void* stream) {
+  DT_REQUIRE(dout && y && mean && invstd && gamma && red && dgamma && dbeta && dy && n_pix > 0 && C > 0 &&
+                 (C & 3) == 0 && P > 0,
+             "bn_bwd_apply: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dt_cdiv(C, 16)), dim3(256), 0, st, red, P, C, dgamma, dbeta);
+  DT_LAUNCH_CHECK();
+  const int64_t n4 = n_pix * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, (const f32x4*)dout,
+                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, gamma, dgamma, dbeta, (f32x4*)dy,
+                     (f32x4*)dres, dres_accumulate, n4, C / 4, (float)(1.0 / (double)n_pix));
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ max-pool 3x3 / stride 2 / pad 1
+__global__ __launch_bounds__(256) void maxpool_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ out,
+                                                      uint32_t* __restrict__ amax, int B, int H, int W, int C4,
+                                                      int Ho, int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    int64_t r = i / C4;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy - 1 + kh;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = 2 * ox - 1 + kw;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = x[(((int64_t)b * H + iy) * W + ix) * C4 + c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // ATen: update when (val > max) || isnan(val); the first valid element always initialises
+          if (first[k] || v[k] > best[k] || v[k] != v[k]) {
+            best[k] = v[k];
+            bi[k] = kh * 3 + kw;
+            first[k] = false;
+          }
+        }
+      }
+    }
+    out[i] = best;
+    if (amax) amax[i] = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  }
+}
+
+extern "C" int dt_maxpool3x3s2(const float* x, float* out, uint8_t* argmax, int B, int H, int W, int C,
+                               void* stream) {
+  DT_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "maxpool: bad args");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x,
+                     (f32x4*)out, (uint32_t*)argmax, B, H, W, C / 4, Ho, Wo);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const f32x4* __restrict__ dout,
+                                                          const uint32_t* __restrict__ amax, f32x4* __restrict__ dx,
+                                                          int acc, int B, int H, int W, int C4, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * H * W * C4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    int64_t r = i / C4;
+    const int ix = (int)(r % W);
+    r /= W;
+    const int iy = (int)(r % H);
+    const int b = (int)(r / H);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    // windows (oy,ox) that contain (iy,ix): 2*oy-1 <= iy <= 2*oy+1
+    const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1;
+    const int ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= Ho) continue;
+      const int kh = iy - (2 * oy - 1);
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= Wo) continue;
+        const int kw = ix - (2 * ox - 1);
+        const uint32_t pos = (uint32_t)(kh * 3 + kw);
+        const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * C4 + c4;
+        const uint32_t am = amax[o];
+        const f32x4 d = dout[o];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (((am >> (8 * k)) & 0xffu) == pos) g[k] += d[k];
+      }
+    }
+    if (acc)
+      dx[i] = dx[i] + g;
+    else
+      dx[i] = g;
+  }
+}
+
+extern "C" int dt_maxpool3x3s2_bwd(const float* dout, const uint8_t* argmax, float* dx, int accumulate, int B,
+                                   int H, int W, int C, void* stream) {
+  DT_REQUIRE(dout && argmax && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "maxpool_bwd: bad args");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)dout, (const uint32_t*)argmax, (f32x4*)dx, accumulate, B, H, W, C / 4, Ho, Wo);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ nearest x2 upsample backward (2x2 sum)
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const f32x4* __restrict__ dup, f32x4* __restrict__ dx,
+                                                             int acc, int B, int H, int W, int C4) {
+  const int64_t total = (int64_t)B * H * W * C4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int W2 = 2 * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    int64_t r = i / C4;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const int64_t base = (((int64_t)b * 2 * H + 2 * y) * W2 + 2 * x) * C4 + c4;
+    f32x4 g = (dup[base] + dup[base + C4]) + (dup[base + (int64_t)W2 * C4] + dup[base + (int64_t)W2 * C4 + C4]);
+    if (acc)
+      dx[i] = dx[i] + g;
+    else
+      dx[i] = g;
+  }
+}
+
+extern "C" int dt_upsample2x_bwd(const float* dup, float* dx, int accumulate, int B, int H, int W, int C,
+                                 void* stream) {
+  DT_REQUIRE(dup && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "upsample2x_bwd: bad args");
+  const int64_t total = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const f32x4*)dup, (f32x4*)dx, accumulate, B, H, W, C / 4);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ layout shuttles
+// NCHW <-> NHWC for small C (image: 3/4 channels; logits: K): one thread per pixel, planar side coalesced.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int B, int C, int64_t HW) {
+  const int64_t total = (int64_t)B * HW;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / HW, p = i - b * HW;
+    for (int c = 0; c < C; ++c) dst[i * C + c] = src[(b * C + c) * HW + p];
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int B, int C, int64_t HW) {
+  const int64_t total = (int64_t)B * HW;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / HW, p = i - b * HW;
+    for (int c = 0; c < C; ++c) dst[(b * C + c) * HW + p] = src[i * C + c];
+  }
+}
+
+extern "C" int dt_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+  DT_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid(B * HW)), dim3(256), 0, (hipStream_t)stream, src, dst, B, C,
+                     HW);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+extern "C" int dt_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+  DT_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad args");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid(B * HW)), dim3(256), 0, (hipStream_t)stream, src, dst, B, C,
+                     HW);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                           int64_t n_pix, int Cs, int Cd, f32x4 mean, f32x4 stdv) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    for (int c = 0; c < Cd; ++c) {
+      // albumentations Normalize(max_pixel_value=255): (x - mean*255) / (std*255), computed in fp32
+      const float v = (float)src[i * Cs + c];
+      dst[i * Cd + c] = (v - mean[c] * 255.f) * (1.f / (stdv[c] * 255.f));
+    }
+  }
+}
+
+extern "C" int dt_normalize_u8(const uint8_t* src, float* dst, int64_t n_pix, int Csrc, int Cdst,
+                               const float* mean, const float* stdv, void* stream) {
+  DT_REQUIRE(src && dst && mean && stdv && n_pix > 0 && Cdst > 0 && Cdst <= 4 && Cdst <= Csrc,
+             "normalize_u8: bad args");
+  f32x4 m = {0, 0, 0, 0}, s = {1, 1, 1, 1};
+  for (int c = 0; c < Cdst; ++c) {
+    m[c] = mean[c];
+    s[c] = stdv[c];
+  }
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3(ew_grid(n_pix)), dim3(256), 0, (hipStream_t)stream, src, dst, n_pix,
+                     Csrc, Cdst, m, s);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

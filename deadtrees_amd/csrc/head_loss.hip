@@ -1,0 +1,431 @@
+// Segmentation head (3x3 conv 16->K + bias, logits NCHW, fused argmax) and the fused
+// softmax + Dice-family / focal / boundary / F-score reductions with their one-pass backward.
+//
+// Replaces on the reference hot path:
+//   smp SegmentationHead conv (reached from deadtrees/network/segmodel.py:214),
+//   logits.softmax(dim=1)                              segmodel.py:216,237,282
+//   class2one_hot                                      deadtrees/loss/losses.py:124-141 (never materialised)
+//   GeneralizedDiceLoss / DiceLoss / FocalLoss / CrossEntropy / SurfaceLoss reductions
+//                                                      loss/gdl.py:10-27, loss/losses.py:187-291
+//   smp Fscore threshold + sums                        segmodel.py:145-149,202-208
+//   argmax(dim=1)                                      segmodel.py:273,289; deployment/inference.py:62
+// All HBM-bound: one read of the 16-channel decoder output / of the logits, wave64 shuffle
+// reductions -> LDS -> one fp64 row per workgroup (fixed-order finalize, no float atomics).
+#include "common.h"
+
+#include <math.h>
+
+#define HEAD_TW 32
+#define HEAD_TH 8
+#define HEAD_MAXK 4
+#define HEAD_CIN 16
+
+// ------------------------------------------------------------------ head forward
+template <int K>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ logits,
+                                                       int64_t* __restrict__ am64, uint8_t* __restrict__ am8, int B,
+                                                       int H, int W) {
+  constexpr int C = HEAD_CIN;
+  constexpr int HH = HEAD_TH + 2, HW_ = HEAD_TW + 2;
+  __shared__ float tile[HH * HW_][C + 1];  // +1: odd pitch -> conflict-free per-pixel reads
+  __shared__ float wl[K * 9 * C];
+  const int tiles_x = (W + HEAD_TW - 1) / HEAD_TW, tiles_y = (H + HEAD_TH - 1) / HEAD_TH;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
+  const int t = threadIdx.x;
+  for (int i = t; i < K * 9 * C; i += 256) wl[i] = w[i];
+  for (int i = t; i < HH * HW_ * (C / 4); i += 256) {
+    const int q = i % (C / 4), pix = i / (C / 4);
+    const int hy = pix / HW_, hx = pix % HW_;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[pix][4 * q + k] = v[k];
+  }
+  __syncthreads();
+  const int py = t / HEAD_TW, px = t % HEAD_TW;
+  const int oy = oy0 + py, ox = ox0 + px;
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  // summation order kh -> kw -> cin (then + bias) per output, fp32 fma
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const float* tp = tile[(py + kh) * HW_ + px + kw];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float xv = tp[c];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(xv, wl[(k * 9 + kh * 3 + kw) * C + c], acc[k]);
+      }
+    }
+  if (oy < H && ox < W) {
+    int best = 0;
+    float bv = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float v = acc[k] + bias[k];
+      logits[(((size_t)b * K + k) * H + oy) * W + ox] = v;
+      if (k == 0 || v > bv) {  // ties -> lowest index (torch.argmax)
+        bv = v;
+        best = k;
+      }
+    }
+    const size_t o = ((size_t)b * H + oy) * W + ox;
+    if (am64) am64[o] = best;
+    if (am8) am8[o] = (uint8_t)best;
+  }
+}
+
+extern "C" int dt_head_fwd(const float* x, const float* w, const float* bias, float* logits, int64_t* am64,
+                           uint8_t* am8, int B, int H, int W, int Cin, int K, void* stream) {
+  DT_REQUIRE(x && w && bias && logits && B > 0 && H > 0 && W > 0, "head_fwd: bad args");
+  DT_REQUIRE(Cin == HEAD_CIN, "head_fwd: Cin must be %d (decoder_channels[-1])", HEAD_CIN);
+  DT_REQUIRE(K >= 1 && K <= HEAD_MAXK, "head_fwd: K=%d unsupported (1..%d)", K, HEAD_MAXK);
+  const int grid = B * dt_cdiv(H, HEAD_TH) * dt_cdiv(W, HEAD_TW);
+  hipStream_t st = (hipStream_t)stream;
+  switch (K) {
+    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+    default: hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+  }
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ head backward
+// dx[b,y,x,c] = sum_{k,kh,kw} dl[b,k,y+1-kh,x+1-kw] * w[k][kh][kw][c]
+// dW[k][kh][kw][c] = sum_pix x[b,y+kh-1,x+kw-1,c] * dl[b,k,y,x] ; dbias[k] = sum dl
+extern "C" int dt_head_bwd_rows(int B, int H, int W) { return B * dt_cdiv(H, HEAD_TH) * dt_cdiv(W, HEAD_TW); }
+
+template <int K>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ dl, float* __restrict__ dx,
+                                                       float* __restrict__ red, int B, int H, int W) {
+  constexpr int C = HEAD_CIN;
+  constexpr int HH = HEAD_TH + 2, HW_ = HEAD_TW + 2;
+  constexpr int NW = K * 9 * C + K;
+  __shared__ float xt[HH * HW_][C + 1];
+  __shared__ float dlt[K][HH * HW_];
+  __shared__ float wl[K * 9 * C];
+  __shared__ float wred[4][NW];
+  const int tiles_x = (W + HEAD_TW - 1) / HEAD_TW, tiles_y = (H + HEAD_TH - 1) / HEAD_TH;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
+  const int t = threadIdx.x;
+  for (int i = t; i < K * 9 * C; i += 256) wl[i] = w[i];
+  for (int i = t; i < HH * HW_ * (C / 4); i += 256) {
+    const int q = i % (C / 4), pix = i / (C / 4);
+    const int hy = pix / HW_, hx = pix % HW_;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xt[pix][4 * q + k] = v[k];
+  }
+  for (int i = t; i < K * HH * HW_; i += 256) {
+    const int k = i / (HH * HW_), pix = i % (HH * HW_);
+    const int hy = pix / HW_, hx = pix % HW_;
+    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = dl[(((size_t)b * K + k) * H + iy) * W + ix];
+    dlt[k][pix] = v;
+  }
+  __syncthreads();
+  const int py = t / HEAD_TW, px = t % HEAD_TW;
+  const int oy = oy0 + py, ox = ox0 + px;
+  const bool valid = oy < H && ox < W;
+  // ---- dx
+  {
+    float a[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) a[c] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        // contribution of output pixel (y+1-kh, x+1-kw) -> halo coords (py+2-kh, px+2-kw)
+        const int hp = (py + 2 - kh) * HW_ + (px + 2 - kw);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const float g = dlt[k][hp];
+#pragma unroll
+          for (int c = 0; c < C; ++c) a[c] = fmaf(g, wl[(k * 9 + kh * 3 + kw) * C + c], a[c]);
+        }
+      }
+    if (valid) {
+      float* o = dx + (((size_t)b * H + oy) * W + ox) * C;
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) {
+        f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(o + 4 * q) = v;
+      }
+    }
+  }
+  // ---- dW / dbias partials: each thread owns its output pixel; wave-reduce each of the NW terms
+  const int lane = t & 63, wave = t >> 6;
+  float g[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) g[k] = valid ? dlt[k][(py + 1) * HW_ + px + 1] : 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float* xp = xt[(py + kh) * HW_ + px + kw];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float v = wave_sum(g[k] * xp[c]);
+          if (lane == 0) wred[wave][(k * 9 + kh * 3 + kw) * C + c] = v;
+        }
+      }
+    const float vb = wave_sum(g[k]);
+    if (lane == 0) wred[wave][K * 9 * C + k] = vb;
+  }
+  __syncthreads();
+  for (int i = t; i < NW; i += 256)
+    red[(size_t)blockIdx.x * NW + i] = (wred[0][i] + wred[1][i]) + (wred[2][i] + wred[3][i]);
+}
+
+extern "C" int dt_head_bwd(const float* x, const float* w, const float* dl, float* dx, float* red, int B, int H,
+                           int W, int Cin, int K, void* stream) {
+  DT_REQUIRE(x && w && dl && dx && red && B > 0 && H > 0 && W > 0, "head_bwd: bad args");
+  DT_REQUIRE(Cin == HEAD_CIN && K >= 1 && K <= HEAD_MAXK, "head_bwd: unsupported Cin/K");
+  const int grid = dt_head_bwd_rows(B, H, W);
+  hipStream_t st = (hipStream_t)stream;
+  switch (K) {
+    case 1: hipLaunchKernelGGL(head_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    case 2: hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    case 3: hipLaunchKernelGGL(head_bwd_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    default: hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+  }
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const float* __restrict__ red, int P, int N,
+                                                         float* __restrict__ out_a, int na,
+                                                         float* __restrict__ out_b) {
+  // out[j] = sum_p red[p][j]; one wave per column group of 4, fp64
+  __shared__ double sh[64][5];
+  const int j0 = blockIdx.x * 4;
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;  // 64 row-lanes
+  double s = 0.0;
+  if (j0 + cl < N)
+    for (int p = rl; p < P; p += 64) s += (double)red[(size_t)p * N + j0 + cl];
+  sh[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && j0 + cl < N) {
+    double tsum = 0.0;
+    for (int i = 0; i < 64; ++i) tsum += sh[i][cl];
+    const int j = j0 + cl;
+    if (j < na)
+      out_a[j] = (float)tsum;
+    else
+      out_b[j - na] = (float)tsum;
+  }
+}
+
+extern "C" int dt_head_bwd_finalize(const float* red, int P, float* dw, float* dbias, int Cin, int K, void* stream) {
+  DT_REQUIRE(red && dw && dbias && P > 0 && Cin == HEAD_CIN && K >= 1 && K <= HEAD_MAXK, "head_bwd_finalize: bad args");
+  const int na = K * 9 * Cin, N = na + K;
+  hipLaunchKernelGGL(colsum_f64_kernel, dim3(dt_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, red, P, N, dw, na,
+                     dbias);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ fused softmax + loss / metric reductions
+#define LOSS_PIX_PER_WG 4096
+
+template <int K>
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restrict__ logits,
+                                                           const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ dist, float gamma,
+                                                           double* __restrict__ part, float* __restrict__ probs,
+                                                           int32_t* __restrict__ err, int64_t HW, int wg_per_img) {
+  // part: [B][wg_per_img][K][NACC] fp64
+  const int b = blockIdx.x / wg_per_img, chunk = blockIdx.x % wg_per_img;
+  const int64_t p0 = (int64_t)chunk * LOSS_PIX_PER_WG;
+  int64_t p1 = p0 + LOSS_PIX_PER_WG;
+  if (p1 > HW) p1 = HW;
+  float acc[K][DT_LOSS_NACC];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < DT_LOSS_NACC; ++j) acc[k][j] = 0.f;
+  const float* lg = logits + (size_t)b * K * HW;
+  for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+    float z[K], pr[K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      z[k] = lg[(size_t)k * HW + p];
+      m = fmaxf(m, z[k]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pr[k] = expf(z[k] - m);
+      sum += pr[k];
+    }
+    const float inv = 1.f / sum;
+    const int64_t lab = labels[(size_t)b * HW + p];
+    if (lab < 0 || lab >= K) err[0] = 1;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float pk = pr[k] * inv;
+      if (probs) probs[((size_t)b * K + k) * HW + p] = pk;
+      const float tk = (lab == k) ? 1.f : 0.f;
+      const float lp = logf(pk + 1e-10f);
+      const float om = 1.f - pk;
+      const float wgt = (gamma == 2.f) ? om * om : (gamma == 0.f ? 1.f : powf(om, gamma));
+      const float hard = pk > 0.5f ? 1.f : 0.f;
+      acc[k][0] += tk;
+      acc[k][1] += pk * tk;
+      acc[k][2] += pk;
+      acc[k][3] += wgt * tk * lp;
+      acc[k][4] += tk * lp;
+      if (dist) acc[k][5] += pk * dist[((size_t)b * K + k) * HW + p];
+      acc[k][6] += tk * hard;
+      acc[k][7] += hard;
+    }
+  }
+  __shared__ double sh[4][K * DT_LOSS_NACC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int j = 0; j < DT_LOSS_NACC; ++j) {
+      const double v = wave_sum_d((double)acc[k][j]);
+      if (lane == 0) sh[wave][k * DT_LOSS_NACC + j] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < K * DT_LOSS_NACC) {
+    const int i = threadIdx.x;
+    part[(size_t)blockIdx.x * K * DT_LOSS_NACC + i] = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+  }
+}
+
+__global__ void seg_loss_finalize_kernel(const double* __restrict__ part, double* __restrict__ acc, int wg_per_img,
+                                         int KN) {
+  // acc[b][i] = sum_chunk part[b][chunk][i]  (fixed order)
+  const int b = blockIdx.x, i = threadIdx.x;
+  if (i < KN) {
+    double s = 0.0;
+    for (int c = 0; c < wg_per_img; ++c) s += part[((size_t)b * wg_per_img + c) * KN + i];
+    acc[(size_t)b * KN + i] = s;
+  }
+}
+
+extern "C" int64_t dt_seg_loss_acc_doubles(int B, int K, int H, int W) {
+  const int64_t wpi = ((int64_t)H * W + LOSS_PIX_PER_WG - 1) / LOSS_PIX_PER_WG;
+  return (int64_t)B * (1 + wpi) * K * DT_LOSS_NACC;
+}
+
+// scratch for partials lives behind acc: caller passes acc sized [B][K][NACC] + partial area; to keep
+// the ABI allocation-free we require acc to have room for B*(1+wg_per_img)*K*NACC doubles.
+extern "C" int dt_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dist, float gamma,
+                               double* acc, float* probs, int32_t* err_flag, int B, int K, int H, int W,
+                               void* stream) {
+  DT_REQUIRE(logits && labels && acc && err_flag && B > 0 && H > 0 && W > 0, "seg_loss_fwd: bad args");
+  DT_REQUIRE(K >= 2 && K <= HEAD_MAXK, "seg_loss_fwd: K=%d unsupported (2..%d)", K, HEAD_MAXK);
+  const int64_t HW = (int64_t)H * W;
+  const int wpi = dt_cdiv(HW, LOSS_PIX_PER_WG);
+  double* part = acc + (size_t)B * K * DT_LOSS_NACC;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = B * wpi;
+  switch (K) {
+    case 2: hipLaunchKernelGGL(seg_loss_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, logits, labels, dist, gamma, part, probs, err_flag, HW, wpi); break;
+    case 3: hipLaunchKernelGGL(seg_loss_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, logits, labels, dist, gamma, part, probs, err_flag, HW, wpi); break;
+    default: hipLaunchKernelGGL(seg_loss_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, dist, gamma, part, probs, err_flag, HW, wpi); break;
+  }
+  DT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(B), dim3(64), 0, st, part, acc, wpi, K * DT_LOSS_NACC);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restrict__ logits,
+                                                           const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ dist,
+                                                           const float* __restrict__ coef,
+                                                           const float* __restrict__ wfocal,
+                                                           const float* __restrict__ wbound,
+                                                           const float* __restrict__ gscale,
+                                                           float* __restrict__ dlogits, int64_t HW, int64_t total) {
+  const float wf = wfocal[0], gamma = wfocal[1];
+  const float gs = gscale ? gscale[0] : 1.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / HW, p = i - b * HW;
+    const float* lg = logits + (size_t)b * K * HW;
+    float z[K], pr[K], g[K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      z[k] = lg[(size_t)k * HW + p];
+      m = fmaxf(m, z[k]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      pr[k] = expf(z[k] - m);
+      sum += pr[k];
+    }
+    const float inv = 1.f / sum;
+    const int64_t lab = labels[i];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float pk = pr[k] * inv;
+      pr[k] = pk;
+      const float tk = (lab == k) ? 1.f : 0.f;
+      float gk = coef[((size_t)b * K + k) * 2] * tk + coef[((size_t)b * K + k) * 2 + 1];
+      if (wf != 0.f && tk != 0.f) {
+        // d/dp [ -(1-p)^gamma * log(p+eps) ] / M
+        const float om = 1.f - pk, pe = pk + 1e-10f;
+        float d;
+        if (gamma == 2.f)
+          d = 2.f * om * logf(pe) - om * om / pe;
+        else if (gamma == 0.f)
+          d = -1.f / pe;
+        else
+          d = gamma * powf(om, gamma - 1.f) * logf(pe) - powf(om, gamma) / pe;
+        gk += wf * d;
+      }
+      if (dist && wbound) gk += wbound[k] * dist[((size_t)b * K + k) * HW + p];
+      g[k] = gk;
+      dot += gk * pk;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) dlogits[((size_t)b * K + k) * HW + p] = gs * pr[k] * (g[k] - dot);
+  }
+}
+
+extern "C" int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dist, const float* coef,
+                               const float* wfocal, const float* wbound, const float* gscale, float* dlogits, int B,
+                               int K, int H, int W, void* stream) {
+  DT_REQUIRE(logits && labels && coef && wfocal && dlogits && B > 0 && H > 0 && W > 0, "seg_loss_bwd: bad args");
+  DT_REQUIRE(K >= 2 && K <= HEAD_MAXK, "seg_loss_bwd: K=%d unsupported", K);
+  const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+  int64_t g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  hipStream_t st = (hipStream_t)stream;
+  switch (K) {
+    case 2: hipLaunchKernelGGL(seg_loss_bwd_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, dlogits, HW, total); break;
+    case 3: hipLaunchKernelGGL(seg_loss_bwd_kernel<3>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, dlogits, HW, total); break;
+    default: hipLaunchKernelGGL(seg_loss_bwd_kernel<4>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, dlogits, HW, total); break;
+  }
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

@@ -1,0 +1,564 @@
+"""MI355X-native U-Net (smp ``Unet`` + ``resnet34`` topology) — the drop-in for ``SemSegment.model``.
+
+Replaces ``smp.Unet(**conf, classes=n)`` built at reference deadtrees/network/segmodel.py:63,85 and
+called at :214/:235/:280 and deployment/inference.py:60.  Same module boundary:
+``forward(x: f32[B,Cin,H,W]) -> logits f32[B,K,H,W]`` and smp-named ``state_dict``.
+
+Inside, nothing is ATen: every convolution / BatchNorm / ReLU / pool / upsample / concat runs in the
+hand-written gfx950 kernels of ``libdeadtrees_hip.so`` through its C ABI (include/deadtrees_hip.h),
+NHWC, with all parameters in ONE flat fp32 buffer (HWIO conv weights) so the optimiser and the RCCL
+gradient all-reduce work on contiguous ranges.  PyTorch only provides device memory, streams and the
+autograd entry point (one ``autograd.Function`` for the whole network; the backward pass is an explicit
+hand-scheduled chain, not an autograd graph).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .spec import ConvSpec, UNetSpec, build_spec
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Saved:
+    """activations kept from forward for the hand-written backward"""
+    __slots__ = ("d",)
+
+    def __init__(self):
+        self.d = {}
+
+
+class UNetEngine:
+    """Executes the layer list of ``UNetSpec`` on the C ABI.  Holds no parameters itself."""
+
+    def __init__(self, spec: UNetSpec):
+        self.spec = spec
+        self.lib = _lib.load()
+        self._ws = {}
+        self.saved: Optional[_Saved] = None
+        self.grad_hook: Optional[Callable[[str, int, int], None]] = None
+
+    # ------------------------------------------------------------------ helpers
+    def _buf(self, name: str, numel: int, dtype=torch.float32, device=None) -> torch.Tensor:
+        t = self._ws.get(name)
+        if t is None or t.numel() < numel or t.device != device:
+            t = torch.empty(max(numel, 1), dtype=dtype, device=device)
+            self._ws[name] = t
+        return t
+
+    def _desc(self, B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split=0, acc=0):
+        return _lib.ConvDesc(B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split, acc)
+
+    def _conv(self, desc, src0, src1, w, out0, out1=None, stats=None):
+        _lib.check(self.lib.dt_conv2d(C.byref(desc), _p(src0), _p(src1), _p(w), _p(out0), _p(out1), _p(stats),
+                                      _stream()), "dt_conv2d")
+
+    # ------------------------------------------------------------------ forward units
+    def _conv_bn(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, training):
+        """y = conv(x); BN statistics -> per-channel scale/shift in bnws.  Returns y, (Ho, Wo)."""
+        dev = src0.device
+        Ho = (Hin + 2 * c.pad - c.k) // c.stride + 1
+        Wo = (Win + 2 * c.pad - c.k) // c.stride + 1
+        C0 = src0.shape[-1]
+        C1 = 0 if src1 is None else src1.shape[-1]
+        assert C0 + C1 == c.cin, (c.key, C0, C1, c.cin)
+        desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
+        y = torch.empty((B, Ho, Wo, c.cout), dtype=torch.float32, device=dev)
+        w = params[c.w_off:c.w_off + c.w_size]
+        nb = self.spec.n_bn_channels
+        mean = bnws[0 * nb + c.bn_off: 0 * nb + c.bn_off + c.cout]
+        invstd = bnws[1 * nb + c.bn_off: 1 * nb + c.bn_off + c.cout]
+        scale = bnws[2 * nb + c.bn_off: 2 * nb + c.bn_off + c.cout]
+        shift = bnws[3 * nb + c.bn_off: 3 * nb + c.bn_off + c.cout]
+        gamma = params[c.g_off:c.g_off + c.cout]
+        beta = params[c.b_off:c.b_off + c.cout]
+        rmean = bnstate[2 * c.bn_off: 2 * c.bn_off + c.cout]
+        rvar = bnstate[2 * c.bn_off + c.cout: 2 * c.bn_off + 2 * c.cout]
+        if training:
+            P = self.lib.dt_conv2d_stat_rows(C.byref(desc))
+            if P <= 0:
+                raise RuntimeError(f"dt_conv2d_stat_rows: {self.lib.dt_last_error().decode()}")
+            stats = self._buf("bn_stats", 2 * P * c.cout, device=dev)
+            self._conv(desc, src0, src1, w, y, None, stats)
+            _lib.check(self.lib.dt_bn_finalize(_p(stats), P, c.cout, float(B * Ho * Wo), _p(gamma), _p(beta),
+                                               BN_EPS, BN_MOMENTUM, _p(rmean), _p(rvar), _p(mean), _p(invstd),
+                                               _p(scale), _p(shift), _stream()), "dt_bn_finalize")
+        else:
+            self._conv(desc, src0, src1, w, y, None, None)
+            _lib.check(self.lib.dt_bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), BN_EPS, c.cout,
+                                                  _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
+        return y, Ho, Wo, (scale, shift)
+
+    def _bn_act(self, y, ss, res=None, res_ss=None, relu=True, out=None):
+        B, H, W, Cc = y.shape
+        z = torch.empty_like(y) if out is None else out
+        _lib.check(self.lib.dt_bn_act(_p(y), _p(ss[0]), _p(ss[1]), _p(res),
+                                      _p(res_ss[0]) if res_ss else None, _p(res_ss[1]) if res_ss else None,
+                                      _p(z), B * H * W, Cc, 1 if relu else 0, _stream()), "dt_bn_act")
+        return z
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x_nchw: torch.Tensor, params: torch.Tensor, bnstate: torch.Tensor, training: bool,
+                save: bool, want_argmax: Optional[str] = None):
+        sp = self.spec
+        if x_nchw.dim() != 4 or x_nchw.shape[1] != sp.in_channels:
+            raise RuntimeError(f"expected input [B,{sp.in_channels},H,W], got {tuple(x_nchw.shape)}")
+        B, Cin, H, W = x_nchw.shape
+        if H % 32 or W % 32:
+            raise RuntimeError(f"H and W must be divisible by 32 (encoder depth 5), got {H}x{W}")
+        if x_nchw.dtype != torch.float32 or not x_nchw.is_cuda:
+            raise RuntimeError("input must be a float32 CUDA/HIP tensor")
+        dev = x_nchw.device
+        x_nchw = x_nchw.contiguous()
+        st = _stream()
+        lib = self.lib
+        sv = _Saved() if save else None
+        bnws = self._buf("bnws", 4 * sp.n_bn_channels, device=dev)
+        if save:
+            # mean/invstd are needed by backward: keep a private copy target per forward
+            bnws = torch.empty(4 * sp.n_bn_channels, dtype=torch.float32, device=dev)
+            sv.d["bnws"] = bnws
+
+        x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
+
+        def keep(key, **kw):
+            if save:
+                sv.d[key] = kw
+
+        # ---- stem
+        y, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, training)
+        f1 = self._bn_act(y, ss)
+        keep("stem", x=x, y=y, z=f1, Hin=H, Win=W)
+        hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+        pool = torch.empty((B, hp, wp, 64), dtype=torch.float32, device=dev)
+        amax = torch.empty((B, hp, wp, 64), dtype=torch.uint8, device=dev) if save else None
+        _lib.check(lib.dt_maxpool3x3s2(_p(f1), _p(pool), _p(amax), B, h, w_, 64, st), "dt_maxpool3x3s2")
+        keep("pool", amax=amax, H=h, W=w_)
+
+        feats = [f1]
+        cur, ch, cw = pool, hp, wp
+        for li, blocks in enumerate(sp.layers):
+            for bi, blk in enumerate(blocks):
+                xin = cur
+                y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw, training)
+                z1 = self._bn_act(y1, ss1)
+                y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, z1, None, 0, B, h1, w1, training)
+                if blk.down is not None:
+                    yd, _, _, ssd = self._conv_bn(blk.down, params, bnstate, bnws, xin, None, 0, B, ch, cw, training)
+                    out = self._bn_act(y2, ss2, res=yd, res_ss=ssd)
+                else:
+                    yd = None
+                    out = self._bn_act(y2, ss2, res=xin)
+                keep(f"L{li}B{bi}", x=xin, y1=y1, z1=z1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
+                cur, ch, cw = out, h2, w2
+            feats.append(cur)
+        # feats = [f1, f2, f3, f4, f5]
+        d, dh, dw = feats[4], ch, cw
+        skips = [feats[3], feats[2], feats[1], feats[0], None]
+        for i, blk in enumerate(sp.decoder):
+            skip = skips[i]
+            Hin, Win = 2 * dh, 2 * dw
+            y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training)
+            z1 = self._bn_act(y1, ss1)
+            y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, z1, None, 0, B, h1, w1, training)
+            z2 = self._bn_act(y2, ss2)
+            keep(f"D{i}", x=d, skip=skip, y1=y1, z1=z1, y2=y2, z2=z2, H=h1, W=w1)
+            d, dh, dw = z2, h2, w2
+
+        # ---- head
+        hd = sp.head
+        K = hd.cout
+        logits = torch.empty((B, K, dh, dw), dtype=torch.float32, device=dev)
+        am64 = am8 = None
+        if want_argmax == "int64":
+            am64 = torch.empty((B, dh, dw), dtype=torch.int64, device=dev)
+        elif want_argmax == "uint8":
+            am8 = torch.empty((B, dh, dw), dtype=torch.uint8, device=dev)
+        wh = params[hd.w_off:hd.w_off + hd.w_size]
+        bh = params[hd.b_off:hd.b_off + K]
+        _lib.check(lib.dt_head_fwd(_p(d), _p(wh), _p(bh), _p(logits), _p(am64), _p(am8), B, dh, dw, hd.cin, K, st),
+                   "dt_head_fwd")
+        keep("head", x=d, H=dh, W=dw)
+        if save:
+            sv.d["B"] = B
+            self.saved = sv
+        return logits, (am64 if am64 is not None else am8)
+
+    # ------------------------------------------------------------------ backward units
+    def _bn_bwd(self, c: ConvSpec, params, grads, bnws, dout, out_act, y, dres=None, dres_acc=False):
+        B, H, W, Cc = y.shape
+        n_pix = B * H * W
+        nb = self.spec.n_bn_channels
+        mean = bnws[c.bn_off: c.bn_off + Cc]
+        invstd = bnws[nb + c.bn_off: nb + c.bn_off + Cc]
+        gamma = params[c.g_off:c.g_off + Cc]
+        P = self.lib.dt_bn_bwd_rows(n_pix, Cc)
+        red = self._buf("bn_red", 2 * P * Cc, device=y.device)
+        st = _stream()
+        _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(red), n_pix, Cc,
+                                             st), "dt_bn_bwd_reduce")
+        dy = torch.empty_like(y)
+        _lib.check(self.lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(red), P,
+                                            _p(grads[c.g_off:c.g_off + Cc]), _p(grads[c.b_off:c.b_off + Cc]),
+                                            _p(dy), _p(dres), 1 if dres_acc else 0, n_pix, Cc, st),
+                   "dt_bn_bwd_apply")
+        return dy
+
+    def _wgrad(self, c: ConvSpec, grads, src0, src1, mode0, B, Hin, Win, dy):
+        Ho, Wo = dy.shape[1], dy.shape[2]
+        C0 = src0.shape[-1]
+        C1 = 0 if src1 is None else src1.shape[-1]
+        desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
+        nbytes = self.lib.dt_conv2d_wgrad_workspace(C.byref(desc))
+        if nbytes == 0:
+            raise RuntimeError(f"dt_conv2d_wgrad_workspace: {self.lib.dt_last_error().decode()}")
+        ws = self._buf("wgrad_ws", nbytes // 4, device=dy.device)
+        _lib.check(self.lib.dt_conv2d_wgrad(C.byref(desc), _p(src0), _p(src1), _p(dy),
+                                            _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
+                                            _stream()), "dt_conv2d_wgrad")
+
+    def _dgrad(self, c: ConvSpec, params, dy, B, Hin, Win, out0, out1=None, split=0, acc=False):
+        """gradient wrt the conv's logical input [B,Hin,Win,cin] (before virtual upsample handling)."""
+        Ho, Wo = dy.shape[1], dy.shape[2]
+        wd = self._buf("wd", c.w_size, device=dy.device)
+        st = _stream()
+        _lib.check(self.lib.dt_weight_flip_transpose(_p(params[c.w_off:c.w_off + c.w_size]), _p(wd), c.k, c.cin,
+                                                     c.cout, st), "dt_weight_flip_transpose")
+        pad = c.k - 1 - c.pad
+        if c.stride == 1:
+            desc = self._desc(B, Ho, Wo, c.cout, 0, 0, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
+        else:
+            assert Hin == 2 * Ho and Win == 2 * Wo
+            desc = self._desc(B, Hin, Win, c.cout, 0, 2, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
+        self._conv(desc, dy, None, wd, out0, out1, None)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits: torch.Tensor, params: torch.Tensor, grads: torch.Tensor):
+        """Hand-scheduled reverse pass.  Writes every parameter gradient into ``grads`` (flat, same layout
+        as ``params``) and calls ``grad_hook(name, lo, hi)`` as each bucket of the flat buffer completes."""
+        sp, lib = self.spec, self.lib
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError("backward called without a saved training forward")
+        S = sv.d
+        B = S["B"]
+        bnws = S["bnws"]
+        dev = dlogits.device
+        st = _stream()
+        dlogits = dlogits.contiguous()
+
+        # ---- head
+        hd = sp.head
+        h = S["head"]
+        H, W = h["H"], h["W"]
+        K = hd.cout
+        g = torch.empty_like(h["x"])
+        P = lib.dt_head_bwd_rows(B, H, W)
+        nw = K * 9 * hd.cin + K
+        red = self._buf("head_red", P * nw, device=dev)
+        wh = params[hd.w_off:hd.w_off + hd.w_size]
+        _lib.check(lib.dt_head_bwd(_p(h["x"]), _p(wh), _p(dlogits), _p(g), _p(red), B, H, W, hd.cin, K, st),
+                   "dt_head_bwd")
+        _lib.check(lib.dt_head_bwd_finalize(_p(red), P, _p(grads[hd.w_off:hd.w_off + hd.w_size]),
+                                            _p(grads[hd.b_off:hd.b_off + K]), hd.cin, K, st), "dt_head_bwd_finalize")
+
+        # ---- decoder (reverse)
+        skip_grads = [None] * 5  # gradient of feats[0..4] = f1..f5
+        for i in range(4, -1, -1):
+            blk = sp.decoder[i]
+            d = S[f"D{i}"]
+            Hh, Ww = d["H"], d["W"]
+            # conv2 + BN + ReLU
+            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"])
+            self._wgrad(blk.conv2, grads, d["z1"], None, 0, B, Hh, Ww, dy2)
+            dz1 = torch.empty_like(d["z1"])
+            self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
+            del dy2
+            dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, d["z1"], d["y1"])
+            del dz1
+            self._wgrad(blk.conv1, grads, d["x"], d["skip"], 1, B, Hh, Ww, dy1)
+            cx = blk.in_ch
+            dup = torch.empty((B, Hh, Ww, cx), dtype=torch.float32, device=dev)
+            if d["skip"] is not None:
+                dskip = torch.empty_like(d["skip"])
+                self._dgrad(blk.conv1, params, dy1, B, Hh, Ww, dup, dskip, split=cx)
+                skip_grads[3 - i] = dskip
+            else:
+                self._dgrad(blk.conv1, params, dy1, B, Hh, Ww, dup)
+            del dy1
+            g = torch.empty_like(d["x"])
+            _lib.check(lib.dt_upsample2x_bwd(_p(dup), _p(g), 0, B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd")
+            del dup
+            S[f"D{i}"] = None
+        if self.grad_hook:
+            self.grad_hook(*sp.buckets[0])
+
+        # g = gradient wrt f5 ; encoder layers in reverse
+        for li in (3, 2, 1, 0):
+            blocks = sp.layers[li]
+            for bi in range(len(blocks) - 1, -1, -1):
+                blk = blocks[bi]
+                r = S[f"L{li}B{bi}"]
+                Hin, Win, Hh, Ww = r["Hin"], r["Win"], r["H"], r["W"]
+                # gradient buffer of the block input; a decoder skip gradient may already live there
+                gin = None
+                gin_has = False
+                if bi == 0 and li > 0 and skip_grads[li] is not None:
+                    gin, gin_has = skip_grads[li], True   # block input of layer(li+1).0 is f_{li+1} = feats[li]
+                if gin is None:
+                    gin = torch.empty_like(r["x"])
+                if blk.down is None:
+                    dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, r["out"], r["y2"], dres=gin,
+                                       dres_acc=gin_has)
+                    gin_has = True
+                    dyd = None
+                else:
+                    gd = torch.empty_like(r["out"])
+                    dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, r["out"], r["y2"], dres=gd)
+                    dyd = self._bn_bwd(blk.down, params, grads, bnws, gd, None, r["yd"])
+                    del gd
+                self._wgrad(blk.conv2, grads, r["z1"], None, 0, B, Hh, Ww, dy2)
+                dz1 = torch.empty_like(r["z1"])
+                self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
+                del dy2
+                dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, r["z1"], r["y1"])
+                del dz1
+                self._wgrad(blk.conv1, grads, r["x"], None, 0, B, Hin, Win, dy1)
+                self._dgrad(blk.conv1, params, dy1, B, Hin, Win, gin, acc=gin_has)
+                gin_has = True
+                del dy1
+                if dyd is not None:
+                    self._wgrad(blk.down, grads, r["x"], None, 0, B, Hin, Win, dyd)
+                    self._dgrad(blk.down, params, dyd, B, Hin, Win, gin, acc=True)
+                    del dyd
+                g = gin
+                S[f"L{li}B{bi}"] = None
+            if li > 0 and self.grad_hook:
+                self.grad_hook(*sp.buckets[4 - li])
+
+        # ---- maxpool + stem
+        pl = S["pool"]
+        stem = S["stem"]
+        gf1 = skip_grads[0]
+        _lib.check(lib.dt_maxpool3x3s2_bwd(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
+                   "dt_maxpool3x3s2_bwd")
+        dy = self._bn_bwd(sp.stem, params, grads, bnws, gf1, stem["z"], stem["y"])
+        self._wgrad(sp.stem, grads, stem["x"], None, 0, B, stem["Hin"], stem["Win"], dy)
+        if self.grad_hook:
+            self.grad_hook(*sp.buckets[4])
+        self.saved = None
+
+
+class _UNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flat, module):
+        logits, _ = module.engine.forward(x, flat.detach(), module.bn_state, module.training, save=True)
+        ctx.module = module
+        module._bn_tracked_inc()
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.module
+        grads = m._grad_buffer()
+        m.engine.backward(dlogits, m.flat_params.detach(), grads)
+        return None, grads, None
+
+
+class UNetHIP(nn.Module):
+    """Drop-in for ``smp.Unet("resnet34", encoder_depth=5, decoder_channels=(256,128,64,32,16),
+    encoder_weights=None, in_channels=C, classes=K)`` on MI355X."""
+
+    def __init__(self, encoder_name: str = "resnet34", encoder_depth: int = 5, encoder_weights=None,
+                 decoder_channels=(256, 128, 64, 32, 16), in_channels: int = 3, classes: int = 2, **unused):
+        super().__init__()
+        if encoder_name != "resnet34":
+            raise NotImplementedError(f"encoder {encoder_name!r}: only resnet34 has HIP kernels")
+        if encoder_depth != 5 or tuple(decoder_channels) != (256, 128, 64, 32, 16):
+            raise NotImplementedError("only encoder_depth=5 / decoder_channels=(256,128,64,32,16)")
+        if encoder_weights is not None:
+            raise NotImplementedError("pretrained encoder weights need a network fetch; load a state_dict instead")
+        self.spec = build_spec(in_channels, classes)
+        self.flat_params = nn.Parameter(torch.zeros(self.spec.n_params, dtype=torch.float32))
+        self.register_buffer("bn_state", torch.zeros(2 * self.spec.n_bn_channels, dtype=torch.float32),
+                             persistent=False)
+        self.register_buffer("num_batches_tracked", torch.zeros(len(self.spec.convs), dtype=torch.int64),
+                             persistent=False)
+        self._engine: Optional[UNetEngine] = None
+        self._grads: Optional[torch.Tensor] = None
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ init / state_dict
+    def reset_parameters(self, seed: Optional[int] = None):
+        """Kaiming-normal conv weights (fan_in, gain sqrt 2), zero biases, BN gamma 1 / beta 0 — what the
+        reference ends with when ``encoder_weights is None`` (segmodel.py:87-89,432-438)."""
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        sd = {}
+        for c in self.spec.convs:
+            fan_in = c.cin * c.k * c.k
+            sd[c.key] = torch.randn((c.cout, c.cin, c.k, c.k), generator=g) * (2.0 / fan_in) ** 0.5
+            if c.bn_key is not None:
+                sd[f"{c.bn_key}.weight"] = torch.ones(c.cout)
+                sd[f"{c.bn_key}.bias"] = torch.zeros(c.cout)
+                sd[f"{c.bn_key}.running_mean"] = torch.zeros(c.cout)
+                sd[f"{c.bn_key}.running_var"] = torch.ones(c.cout)
+                sd[f"{c.bn_key}.num_batches_tracked"] = torch.tensor(0)
+            else:
+                sd[c.key.replace(".weight", ".bias")] = torch.zeros(c.cout)
+        self.load_smp_state_dict(sd)
+
+    @torch.no_grad()
+    def load_smp_state_dict(self, sd, strict: bool = True):
+        """smp/torch layout (OIHW conv weights) -> flat HWIO buffer."""
+        flat = torch.zeros(self.spec.n_params, dtype=torch.float32)
+        bn = torch.zeros(2 * self.spec.n_bn_channels, dtype=torch.float32)
+        nbt = torch.zeros(len(self.spec.convs), dtype=torch.int64)
+        missing = []
+
+        def get(k, shape):
+            if k not in sd:
+                missing.append(k)
+                return None
+            t = sd[k].detach().to("cpu", torch.float32)
+            if tuple(t.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(t.shape)} vs {tuple(shape)}")
+            return t
+
+        for c in self.spec.convs:
+            w = get(c.key, (c.cout, c.cin, c.k, c.k))
+            if w is not None:
+                if c.bn_key is not None:
+                    flat[c.w_off:c.w_off + c.w_size] = w.permute(2, 3, 1, 0).reshape(-1)   # HWIO
+                else:
+                    flat[c.w_off:c.w_off + c.w_size] = w.permute(0, 2, 3, 1).reshape(-1)   # head: OHWI
+            if c.bn_key is not None:
+                for name, off in (("weight", c.g_off), ("bias", c.b_off)):
+                    t = get(f"{c.bn_key}.{name}", (c.cout,))
+                    if t is not None:
+                        flat[off:off + c.cout] = t
+                rm = get(f"{c.bn_key}.running_mean", (c.cout,))
+                rv = get(f"{c.bn_key}.running_var", (c.cout,))
+                if rm is not None:
+                    bn[2 * c.bn_off:2 * c.bn_off + c.cout] = rm
+                if rv is not None:
+                    bn[2 * c.bn_off + c.cout:2 * c.bn_off + 2 * c.cout] = rv
+                k = f"{c.bn_key}.num_batches_tracked"
+                if k in sd:
+                    nbt[c.index] = int(sd[k])
+            else:
+                t = get(c.key.replace(".weight", ".bias"), (c.cout,))
+                if t is not None:
+                    flat[c.b_off:c.b_off + c.cout] = t
+        if strict and missing:
+            raise RuntimeError(f"missing keys in state_dict: {missing[:8]}{'...' if len(missing) > 8 else ''}")
+        self.flat_params.data.copy_(flat.to(self.flat_params.device))
+        self.bn_state.copy_(bn.to(self.bn_state.device))
+        self.num_batches_tracked.copy_(nbt.to(self.num_batches_tracked.device))
+        return missing
+
+    def smp_state_dict(self, prefix: str = ""):
+        """flat HWIO buffer -> smp/torch-named tensors (what ``smp.Unet.state_dict()`` would hold)."""
+        flat = self.flat_params.detach().cpu()
+        bn = self.bn_state.detach().cpu()
+        nbt = self.num_batches_tracked.cpu()
+        out = {}
+        for c in self.spec.convs:
+            w = flat[c.w_off:c.w_off + c.w_size]
+            if c.bn_key is not None:
+                out[prefix + c.key] = w.reshape(c.k, c.k, c.cin, c.cout).permute(3, 2, 0, 1).contiguous()
+                out[prefix + f"{c.bn_key}.weight"] = flat[c.g_off:c.g_off + c.cout].clone()
+                out[prefix + f"{c.bn_key}.bias"] = flat[c.b_off:c.b_off + c.cout].clone()
+                out[prefix + f"{c.bn_key}.running_mean"] = bn[2 * c.bn_off:2 * c.bn_off + c.cout].clone()
+                out[prefix + f"{c.bn_key}.running_var"] = bn[2 * c.bn_off + c.cout:2 * c.bn_off + 2 * c.cout].clone()
+                out[prefix + f"{c.bn_key}.num_batches_tracked"] = nbt[c.index].clone()
+            else:
+                out[prefix + c.key] = w.reshape(c.cout, c.k, c.k, c.cin).permute(0, 3, 1, 2).contiguous()
+                out[prefix + c.key.replace(".weight", ".bias")] = flat[c.b_off:c.b_off + c.cout].clone()
+        return out
+
+    # nn.Module protocol: expose smp keys so Lightning checkpoints stay interchangeable with the reference
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        destination.update(self.smp_state_dict(prefix))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        sub = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        try:
+            miss = self.load_smp_state_dict(sub, strict=False)
+            missing_keys.extend(prefix + m for m in miss)
+        except RuntimeError as e:  # size mismatch
+            error_msgs.append(str(e))
+
+    def smp_grad_dict(self):
+        """parameter gradients under smp names / OIHW layout (parity tests, debugging)."""
+        g = self._grad_buffer().detach().cpu()
+        out = {}
+        for c in self.spec.convs:
+            w = g[c.w_off:c.w_off + c.w_size]
+            if c.bn_key is not None:
+                out[c.key] = w.reshape(c.k, c.k, c.cin, c.cout).permute(3, 2, 0, 1).contiguous()
+                out[f"{c.bn_key}.weight"] = g[c.g_off:c.g_off + c.cout].clone()
+                out[f"{c.bn_key}.bias"] = g[c.b_off:c.b_off + c.cout].clone()
+            else:
+                out[c.key] = w.reshape(c.cout, c.k, c.k, c.cin).permute(0, 3, 1, 2).contiguous()
+                out[c.key.replace(".weight", ".bias")] = g[c.b_off:c.b_off + c.cout].clone()
+        return out
+
+    # ------------------------------------------------------------------ execution
+    @property
+    def engine(self) -> UNetEngine:
+        if self._engine is None:
+            self._engine = UNetEngine(self.spec)
+        return self._engine
+
+    def _grad_buffer(self) -> torch.Tensor:
+        if self._grads is None or self._grads.device != self.flat_params.device:
+            self._grads = torch.zeros_like(self.flat_params.data)
+        return self._grads
+
+    def _bn_tracked_inc(self):
+        if self.training:
+            self.num_batches_tracked += 1
+
+    def _require_gpu(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("deadtrees_amd.UNetHIP runs only on an MI355X (HIP) device; there is no CPU fallback")
+        if self.flat_params.device != x.device:
+            raise RuntimeError(f"model on {self.flat_params.device}, input on {x.device}: call model.to(device)")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._require_gpu(x)
+        x = x.float()
+        if torch.is_grad_enabled() and self.flat_params.requires_grad:
+            return _UNetFunction.apply(x, self.flat_params, self)
+        logits, _ = self.engine.forward(x, self.flat_params.detach(), self.bn_state, self.training, save=False)
+        self._bn_tracked_inc()
+        return logits
+
+    @torch.no_grad()
+    def predict_classes(self, x: torch.Tensor, dtype: str = "int64") -> torch.Tensor:
+        """forward + argmax fused in the head kernel (deployment/inference.py:60-62), eval-mode BN."""
+        self._require_gpu(x)
+        was = self.training
+        self.eval()
+        try:
+            _, am = self.engine.forward(x.float(), self.flat_params.detach(), self.bn_state, False, save=False,
+                                        want_argmax=dtype)
+        finally:
+            self.train(was)
+        return am

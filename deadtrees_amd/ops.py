@@ -1,0 +1,251 @@
+"""Thin tensor-level wrappers over the C ABI (one python function per ``dt_*`` entry point).
+
+Every function takes/returns torch HIP tensors, validates nothing beyond what the C side validates,
+and raises RuntimeError when the library reports an error.  Used by the engine-independent callers
+(tiled inference, optimiser) and by the parity tests, which therefore exercise the C ABI itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("deadtrees_amd ops need HIP device tensors (no CPU fallback)")
+
+
+def conv_desc(B, Hin, Win, C0, C1, mode0, Cout, k, stride, pad, split=0, acc=0):
+    Ho = (Hin + 2 * pad - k) // stride + 1
+    Wo = (Win + 2 * pad - k) // stride + 1
+    return _lib.ConvDesc(B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split, acc)
+
+
+def conv2d(src0, w_hwio, k, stride, pad, src1=None, mode0=0, split=0, out0=None, out1=None, accumulate=False,
+           want_stats=False):
+    """NHWC conv through dt_conv2d.  Returns (out0, out1, stats[2,P,Cout] or None)."""
+    _gpu(src0, src1, w_hwio)
+    lib = _lib.load()
+    B = src0.shape[0]
+    C0 = src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    if mode0 == 0:
+        Hin, Win = src0.shape[1], src0.shape[2]
+    else:
+        Hin, Win = 2 * src0.shape[1], 2 * src0.shape[2]
+    Cout = w_hwio.shape[-1]
+    d = conv_desc(B, Hin, Win, C0, C1, mode0, Cout, k, stride, pad, split, 1 if accumulate else 0)
+    dev = src0.device
+    if out0 is None:
+        out0 = torch.empty((B, d.Ho, d.Wo, split if split else Cout), dtype=torch.float32, device=dev)
+    if split and out1 is None:
+        out1 = torch.empty((B, d.Ho, d.Wo, Cout - split), dtype=torch.float32, device=dev)
+    stats = None
+    if want_stats:
+        P = lib.dt_conv2d_stat_rows(C.byref(d))
+        if P <= 0:
+            raise RuntimeError(lib.dt_last_error().decode())
+        stats = torch.empty((2, P, Cout), dtype=torch.float32, device=dev)
+    _lib.check(lib.dt_conv2d(C.byref(d), _p(src0), _p(src1), _p(w_hwio.contiguous()), _p(out0), _p(out1), _p(stats),
+                             _st()), "dt_conv2d")
+    return out0, out1, stats
+
+
+def weight_flip_transpose(w_hwio):
+    _gpu(w_hwio)
+    k, _, cin, cout = w_hwio.shape
+    wd = torch.empty((k, k, cout, cin), dtype=torch.float32, device=w_hwio.device)
+    _lib.check(_lib.load().dt_weight_flip_transpose(_p(w_hwio.contiguous()), _p(wd), k, cin, cout, _st()),
+               "dt_weight_flip_transpose")
+    return wd
+
+
+def conv2d_wgrad(src0, dy, k, stride, pad, src1=None, mode0=0):
+    _gpu(src0, src1, dy)
+    lib = _lib.load()
+    B = src0.shape[0]
+    C0 = src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    Hin, Win = (src0.shape[1], src0.shape[2]) if mode0 == 0 else (2 * src0.shape[1], 2 * src0.shape[2])
+    Cout = dy.shape[-1]
+    d = conv_desc(B, Hin, Win, C0, C1, mode0, Cout, k, stride, pad)
+    assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2]), ((d.Ho, d.Wo), dy.shape)
+    nbytes = lib.dt_conv2d_wgrad_workspace(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError(lib.dt_last_error().decode())
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+    dw = torch.empty((k, k, C0 + C1, Cout), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.dt_conv2d_wgrad(C.byref(d), _p(src0), _p(src1), _p(dy.contiguous()), _p(dw), _p(ws), nbytes, _st()),
+               "dt_conv2d_wgrad")
+    return dw
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    _gpu(stats, gamma, beta)
+    _, P, Cc = stats.shape
+    dev = stats.device
+    mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
+    _lib.check(_lib.load().dt_bn_finalize(_p(stats), P, Cc, float(count), _p(gamma), _p(beta), eps, momentum,
+                                          _p(running_mean), _p(running_var), _p(mean), _p(invstd), _p(scale),
+                                          _p(shift), _st()), "dt_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_act(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
+    _gpu(y, scale, shift, res)
+    out = torch.empty_like(y)
+    n_pix = y.numel() // y.shape[-1]
+    _lib.check(_lib.load().dt_bn_act(_p(y), _p(scale), _p(shift), _p(res), _p(rscale), _p(rshift), _p(out), n_pix,
+                                     y.shape[-1], 1 if relu else 0, _st()), "dt_bn_act")
+    return out
+
+
+def bn_backward(dout, out_act, y, mean, invstd, gamma, want_dres=False):
+    _gpu(dout, y)
+    lib = _lib.load()
+    Cc = y.shape[-1]
+    n_pix = y.numel() // Cc
+    P = lib.dt_bn_bwd_rows(n_pix, Cc)
+    red = torch.empty((2, P, Cc), dtype=torch.float32, device=y.device)
+    _lib.check(lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(red), n_pix, Cc, _st()),
+               "dt_bn_bwd_reduce")
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty_like(dgamma)
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    _lib.check(lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(red), P,
+                                   _p(dgamma), _p(dbeta), _p(dy), _p(dres), 0, n_pix, Cc, _st()), "dt_bn_bwd_apply")
+    return dy, dgamma, dbeta, dres
+
+
+def maxpool3x3s2(x, want_argmax=True):
+    _gpu(x)
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float32, device=x.device)
+    am = torch.empty((B, Ho, Wo, Cc), dtype=torch.uint8, device=x.device) if want_argmax else None
+    _lib.check(_lib.load().dt_maxpool3x3s2(_p(x), _p(out), _p(am), B, H, W, Cc, _st()), "dt_maxpool3x3s2")
+    return out, am
+
+
+def maxpool3x3s2_bwd(dout, argmax, H, W, dx=None):
+    _gpu(dout, argmax)
+    B, _, _, Cc = dout.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty((B, H, W, Cc), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.load().dt_maxpool3x3s2_bwd(_p(dout), _p(argmax), _p(dx), 1 if acc else 0, B, H, W, Cc, _st()),
+               "dt_maxpool3x3s2_bwd")
+    return dx
+
+
+def upsample2x_bwd(dup):
+    _gpu(dup)
+    B, H2, W2, Cc = dup.shape
+    dx = torch.empty((B, H2 // 2, W2 // 2, Cc), dtype=torch.float32, device=dup.device)
+    _lib.check(_lib.load().dt_upsample2x_bwd(_p(dup), _p(dx), 0, B, H2 // 2, W2 // 2, Cc, _st()), "dt_upsample2x_bwd")
+    return dx
+
+
+def nchw_to_nhwc(x):
+    _gpu(x)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dt_nchw_to_nhwc(_p(x.contiguous()), _p(out), B, Cc, H, W, _st()), "dt_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    _gpu(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().dt_nhwc_to_nchw(_p(x.contiguous()), _p(out), B, Cc, H, W, _st()), "dt_nhwc_to_nchw")
+    return out
+
+
+def normalize_u8(src_u8_nhwc, mean, std, c_dst):
+    """uint8 [..., Csrc] -> f32 [..., c_dst] with (x - 255*mean) / (255*std)  (deadtreedata.py:148-154)."""
+    _gpu(src_u8_nhwc)
+    cs = src_u8_nhwc.shape[-1]
+    n_pix = src_u8_nhwc.numel() // cs
+    out = torch.empty(tuple(src_u8_nhwc.shape[:-1]) + (c_dst,), dtype=torch.float32, device=src_u8_nhwc.device)
+    m = (C.c_float * c_dst)(*[float(v) for v in mean[:c_dst]])
+    s = (C.c_float * c_dst)(*[float(v) for v in std[:c_dst]])
+    _lib.check(_lib.load().dt_normalize_u8(_p(src_u8_nhwc.contiguous()), _p(out), n_pix, cs, c_dst, m, s, _st()),
+               "dt_normalize_u8")
+    return out
+
+
+def head_fwd(x, w_ohwi, bias, argmax: Optional[str] = None):
+    _gpu(x, w_ohwi, bias)
+    B, H, W, Cin = x.shape
+    K = w_ohwi.shape[0]
+    logits = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
+    a64 = torch.empty((B, H, W), dtype=torch.int64, device=x.device) if argmax == "int64" else None
+    a8 = torch.empty((B, H, W), dtype=torch.uint8, device=x.device) if argmax == "uint8" else None
+    _lib.check(_lib.load().dt_head_fwd(_p(x), _p(w_ohwi.contiguous()), _p(bias), _p(logits), _p(a64), _p(a8), B, H, W,
+                                       Cin, K, _st()), "dt_head_fwd")
+    return logits, (a64 if a64 is not None else a8)
+
+
+def head_bwd(x, w_ohwi, dlogits):
+    _gpu(x, w_ohwi, dlogits)
+    lib = _lib.load()
+    B, H, W, Cin = x.shape
+    K = w_ohwi.shape[0]
+    P = lib.dt_head_bwd_rows(B, H, W)
+    nw = K * 9 * Cin + K
+    red = torch.empty((P, nw), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    _lib.check(lib.dt_head_bwd(_p(x), _p(w_ohwi.contiguous()), _p(dlogits.contiguous()), _p(dx), _p(red), B, H, W, Cin,
+                               K, _st()), "dt_head_bwd")
+    dw = torch.empty_like(w_ohwi)
+    db = torch.empty(K, dtype=torch.float32, device=x.device)
+    _lib.check(lib.dt_head_bwd_finalize(_p(red), P, _p(dw), _p(db), Cin, K, _st()), "dt_head_bwd_finalize")
+    return dx, dw, db
+
+
+class FlatAdam:
+    """clip_grad_norm_(max_norm) + torch.optim.Adam on one flat buffer, two fused HIP passes
+    (reference: configs/trainer/default.yaml:18 + segmodel.py:420-425)."""
+
+    def __init__(self, params: torch.Tensor, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm: float = 0.5):
+        _gpu(params)
+        self.p = params
+        self.m = torch.zeros_like(params)
+        self.v = torch.zeros_like(params)
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.t = 0
+        lib = _lib.load()
+        self.rows = lib.dt_sumsq_rows(params.numel())
+        self.partial = torch.empty(self.rows, dtype=torch.float64, device=params.device)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=params.device)
+        self.coef = torch.ones(1, dtype=torch.float32, device=params.device)
+
+    def step(self, grads: torch.Tensor, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None,
+             lr: Optional[float] = None):
+        lib = _lib.load()
+        n = self.p.numel()
+        st = _st()
+        self.t += 1
+        _lib.check(lib.dt_sumsq(_p(grads), n, _p(self.partial), st), "dt_sumsq")
+        _lib.check(lib.dt_clip_coef(_p(self.partial), self.rows, float(self.max_norm or 0.0), float(grad_scale),
+                                    _p(self.norm), _p(self.coef), st), "dt_clip_coef")
+        b1, b2 = self.betas
+        _lib.check(lib.dt_adam_step(_p(self.p), _p(grads), _p(self.m), _p(self.v), n,
+                                    float(self.lr if lr is None else lr), b1, b2, self.eps, 1.0 - b1 ** self.t,
+                                    1.0 - b2 ** self.t, _p(self.coef), _p(skip_flag), st), "dt_adam_step")
+        return self.norm

@@ -1,0 +1,168 @@
+/* deadtrees_hip.h — C ABI of libdeadtrees_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (cwerner/deadtrees) has NO native code and no FFI: its hot path is
+ * `self.model(img)` (deadtrees/network/segmodel.py:214,235,280; deployment/inference.py:60) on
+ * smp.Unet(resnet34) plus the loss callables of deadtrees/loss (segmodel.py:169-200), executed
+ * by ATen.  Each entry point below replaces one ATen op family that this path launches
+ * (SURVEY.md §2.3 K1..K22); the comment on each names the reference call site it serves.
+ *
+ * Conventions
+ *   - plain pointers + sizes; all tensors are DEVICE pointers, fp32 unless stated, NHWC
+ *     ("[B,H,W,C]") for activations, HWIO ("[kh][kw][Cin][Cout]") for conv weights;
+ *     logits / labels / distance maps at the module boundary are NCHW like the reference.
+ *   - inputs are borrowed, outputs are caller-allocated, no ownership transfer, no hidden
+ *     allocation, no host synchronisation: every call only enqueues kernels on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream) and is hipGraph-capturable.
+ *   - return 0 on success, a negative DT_E* code otherwise; dt_last_error() gives the message
+ *     (thread-local).  Shape preconditions are validated on the host BEFORE any launch.
+ */
+#ifndef DEADTREES_HIP_H
+#define DEADTREES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DT_OK 0
+#define DT_EINVAL (-22)  /* bad shape / argument            */
+#define DT_ENOSYS (-38)  /* configuration not implemented   */
+#define DT_EHIP (-5)     /* HIP runtime / launch failure    */
+
+const char* dt_last_error(void);
+int dt_version(void);
+/* number of HIP devices visible; <0 on error.  Does not create a context. */
+int dt_device_count(void);
+
+/* ------------------------------------------------------------------ convolution (K1,K5,K6,K7,K9,K10,K21)
+ * One descriptor drives forward, data-gradient and weight-gradient kernels.
+ * The LOGICAL input is cat([src0', src1], channel) of size [B,Hin,Win,C0+C1] where src0' is
+ *   mode0 = 0 : src0 itself                                   [B,Hin,Win,C0]
+ *   mode0 = 1 : nearest x2 upsample of src0                   [B,Hin/2,Win/2,C0]  (F.interpolate, K9)
+ *   mode0 = 2 : zero-insertion x2 of src0 (transposed conv)   [B,Hin/2,Win/2,C0]  (stride-2 dgrad)
+ * src1 (C1 may be 0) is always direct (the U-Net skip, torch.cat K10).
+ * Output [B,Ho,Wo,Cout]; channels [0,cout_split) go to out0 (leading dim cout_split), the rest to
+ * out1 (leading dim Cout-cout_split); cout_split = 0 -> everything to out0.
+ */
+typedef struct dt_conv_desc {
+  int32_t B, Hin, Win;
+  int32_t C0, C1;
+  int32_t mode0;
+  int32_t Ho, Wo, Cout;
+  int32_t ksize;       /* 1, 3 or 7 (square) */
+  int32_t stride;      /* 1 or 2             */
+  int32_t pad;
+  int32_t cout_split;  /* 0 or a multiple of 32 */
+  int32_t accumulate;  /* !=0: out0 += result (gradient accumulation on residual / skip joins) */
+} dt_conv_desc;
+
+/* rows P of the BatchNorm partial-statistics buffer dt_conv2d writes: stats is [2][P][Cout]
+ * (plane 0 = sum, plane 1 = sum of squares, one row per workgroup tile). */
+int dt_conv2d_stat_rows(const dt_conv_desc* d);
+
+/* y = conv(x, w) — replaces ATen conv2d reached from smp encoder/decoder (segmodel.py:214).
+ * stats may be NULL.  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fma chains. */
+int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const float* w_hwio,
+              float* out0, float* out1, float* stats, void* stream);
+
+/* wd[kh'][kw'][co][ci] = w[K-1-kh'][K-1-kw'][ci][co]: weights of the data-gradient convolution. */
+int dt_weight_flip_transpose(const float* w_hwio, float* wd, int ksize, int Cin, int Cout, void* stream);
+
+/* dW[kh][kw][ci][co] = sum_{b,oy,ox} x[b,oy*s+kh-p,ox*s+kw-p,ci] * dy[b,oy,ox,co]  (autograd of conv2d, K21).
+ * workspace: fp32 scratch of at least dt_conv2d_wgrad_workspace(d) bytes (split-K partials, reduced
+ * in a fixed order -> run-to-run deterministic). */
+size_t dt_conv2d_wgrad_workspace(const dt_conv_desc* d);
+int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy,
+                    float* dw_hwio, float* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm / ReLU / residual (K2,K3,K8,K21) */
+/* stats[2][P][C] -> batch mean / biased var over `count` elements; writes mean, invstd, and the fused
+ * affine scale = gamma*invstd, shift = beta - mean*scale; updates running stats with `momentum`
+ * (unbiased var), as torch BatchNorm2d(train).  fp64 accumulation, fixed order. */
+int dt_bn_finalize(const float* stats, int P, int C, double count, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running stats. */
+int dt_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* out = act( y*scale[c]+shift[c] + (res ? res*rscale[c]+rshift[c] : 0) ), act = ReLU if relu!=0.
+ * rscale/rshift NULL -> identity residual.  n_pix = B*H*W. */
+int dt_bn_act(const float* y, const float* scale, const float* shift, const float* res,
+              const float* rscale, const float* rshift, float* out, int64_t n_pix, int C, int relu,
+              void* stream);
+/* BN backward, pass 1: g = dout * (out>0 if out_act else 1); partial sums of g and g*xhat per channel
+ * -> red[2][P][C] with P = dt_bn_bwd_rows(n_pix). */
+int dt_bn_bwd_rows(int64_t n_pix, int C);
+int dt_bn_bwd_reduce(const float* dout, const float* out_act, const float* y, const float* mean,
+                     const float* invstd, float* red, int64_t n_pix, int C, void* stream);
+/* pass 2: reduces red -> dgamma, dbeta (fp64, fixed order) and writes
+ * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));  if dres != NULL also dres (+)= g. */
+int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
+                    const float* invstd, const float* gamma, const float* red, int P,
+                    float* dgamma, float* dbeta, float* dy, float* dres, int dres_accumulate,
+                    int64_t n_pix, int C, void* stream);
+
+/* ------------------------------------------------------------------ pooling / resampling (K4,K9 bwd) */
+/* max_pool2d(k=3,s=2,p=1) NHWC; argmax (uint8 window position, first max in scan order like ATen). */
+int dt_maxpool3x3s2(const float* x, float* out, uint8_t* argmax, int B, int H, int W, int C, void* stream);
+int dt_maxpool3x3s2_bwd(const float* dout, const uint8_t* argmax, float* dx, int accumulate, int B,
+                        int H, int W, int C, void* stream);
+/* backward of nearest x2 upsample: dx[b,y,x,c] = sum of the 2x2 block of dup; dup is [B,2H,2W,C]. */
+int dt_upsample2x_bwd(const float* dup, float* dx, int accumulate, int B, int H, int W, int C, void* stream);
+/* layout shuttles at the module boundary */
+int dt_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+int dt_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+/* uint8 HWC tile -> normalised fp32 NHWC ((x/255-mean)/std), reference data/deadtreedata.py:148-154 */
+/* mean/std are HOST arrays of Cdst floats (passed by value to the kernel). */
+int dt_normalize_u8(const uint8_t* src, float* dst, int64_t n_pix, int Csrc, int Cdst, const float* mean,
+                    const float* std, void* stream);
+
+/* ------------------------------------------------------------------ segmentation head (K11,K12,K19) */
+/* logits[B,K,H,W] (NCHW) = conv3x3(x[B,H,W,Cin], w[K][3][3][Cin]) + bias; optional uint8/int64 argmax
+ * class map (ties -> lowest index, torch.argmax) — smp SegmentationHead + inference.py:62. */
+int dt_head_fwd(const float* x, const float* w_ohwi, const float* bias, float* logits_nchw,
+                int64_t* argmax_i64, uint8_t* argmax_u8, int B, int H, int W, int Cin, int K, void* stream);
+int dt_head_bwd_rows(int B, int H, int W);
+/* dx[B,H,W,Cin], partial dW/dbias rows -> red[P][K*9*Cin + K]; dt_head_bwd_finalize sums them. */
+int dt_head_bwd(const float* x, const float* w_ohwi, const float* dlogits_nchw, float* dx, float* red,
+                int B, int H, int W, int Cin, int K, void* stream);
+int dt_head_bwd_finalize(const float* red, int P, float* dw_ohwi, float* dbias, int Cin, int K, void* stream);
+
+/* ------------------------------------------------------------------ losses & metrics (K12-K18) */
+#define DT_LOSS_NACC 8
+/* per (b,k) accumulators, fp64 [B][K][DT_LOSS_NACC]:
+ *   0 count(t)  1 sum p*t  2 sum p  3 sum (1-p)^gamma * t * log(p+1e-10)  4 sum t*log(p+1e-10)
+ *   5 sum p*dist  6 sum t*[p>0.5]  7 sum [p>0.5]
+ * from logits (softmax fused, never materialising the int32 one-hot of losses.py:124-141).
+ * labels int64 [B,H,W]; dist may be NULL.  Also optionally writes probs[B,K,H,W].
+ * acc must have room for dt_seg_loss_acc_doubles(B,K,H,W) doubles: the [B][K][NACC] result first,
+ * per-workgroup partial rows behind it (fixed-order second stage, no atomics).
+ * Labels outside [0,K) (the assert of losses.py:129) set err_flag[0]=1 instead of aborting the kernel. */
+int64_t dt_seg_loss_acc_doubles(int B, int K, int H, int W);
+int dt_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dist, float gamma,
+                    double* acc, float* probs, int32_t* err_flag, int B, int K, int H, int W, void* stream);
+/* dlogits = softmax-backward of g, g_k = a[b,k]*t_k + c[b,k] + wf*focal'(p_k)*t_k + wb[k]*dist_k,
+ * scaled by gscale[0] (device scalar: upstream grad); coef fp32 [B][K][2] = (a,c); wfocal = [wf/M, gamma]. */
+int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dist, const float* coef,
+                    const float* wfocal, const float* wbound, const float* gscale, float* dlogits,
+                    int B, int K, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ optimiser (K22) */
+/* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
+int dt_sumsq_rows(int64_t n);
+int dt_sumsq(const float* g, int64_t n, double* partial, void* stream);
+/* norm[0] = sqrt(sum partial) ; clipcoef[0] = min(1, max_norm/(norm+1e-6)) * gscale  (clip_grad_norm_) */
+int dt_clip_coef(const double* partial, int rows, float max_norm, float gscale, float* norm, float* clipcoef,
+                 void* stream);
+/* torch.optim.Adam step on a flat buffer (segmodel.py:420-425): g' = g*clipcoef[0];
+ * skipped entirely when skip_flag[0] != 0 (non-finite loss: segmodel.py:220-222). */
+int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float bias_c1, float bias_c2, const float* clipcoef, const int32_t* skip_flag,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEADTREES_HIP_H */

@@ -1,0 +1,255 @@
+"""Per-kernel parity of the C ABI (through deadtrees_amd.ops) against torch CPU fp64 primitives.
+All tests need an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from deadtrees_amd import ops
+    return ops
+
+
+def nhwc(t):  # NCHW cpu -> NHWC gpu f32
+    return t.permute(0, 2, 3, 1).contiguous().float().to(DEV)
+
+
+def to_nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).double()
+
+
+def hwio(w):  # OIHW -> HWIO gpu
+    return w.permute(2, 3, 1, 0).contiguous().float().to(DEV)
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 32, 32, 64, 64, 3, 1, 1),
+    (1, 40, 24, 16, 16, 3, 1, 1),     # ragged tiles, narrow channels (dec.4 shape)
+    (2, 16, 16, 128, 96, 3, 1, 1),    # TW=16 path, Cout not multiple of 64
+    (3, 8, 8, 32, 48, 3, 1, 1),       # TW=8 path
+    (2, 2, 2, 64, 64, 3, 1, 1),       # tiny map (layer4 of a 64x64 tile)
+    (2, 32, 32, 64, 128, 3, 2, 1),    # layer2.0.conv1
+    (2, 12, 20, 32, 64, 3, 2, 1),
+    (2, 32, 32, 64, 128, 1, 2, 0),    # downsample
+    (2, 64, 96, 3, 64, 7, 2, 3),      # stem
+    (1, 32, 32, 4, 64, 7, 2, 3),      # stem, RGBN
+    (1, 34, 70, 512, 64, 3, 1, 1),    # many input chunks, width > 2 tiles
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CONV_CASES)
+def test_conv_fwd_and_stats(B, H, W, Cin, Cout, k, s, p):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), stride=s, padding=p)
+    y, _, stats = ops.conv2d(nhwc(x), hwio(w), k, s, p, want_stats=True)
+    torch.cuda.synchronize()
+    got = to_nchw(y)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < 2e-6
+    s1 = stats[0].double().sum(0).cpu()
+    s2 = stats[1].double().sum(0).cpu()
+    np.testing.assert_allclose(s1, ref.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4 * ref.abs().sum(dim=(0, 2, 3)).max())
+    np.testing.assert_allclose(s2, (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-5)
+
+
+def test_conv_upsample_concat_split_accumulate():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, h, w_, C0, C1, Cout = 2, 10, 12, 64, 32, 96
+    a = torch.randn((B, C0, h, w_), generator=g)
+    skip = torch.randn((B, C1, 2 * h, 2 * w_), generator=g)
+    wt = torch.randn((Cout, C0 + C1, 3, 3), generator=g) * 0.05
+    xin = torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), skip], dim=1)
+    ref = F.conv2d(xin.double(), wt.double(), padding=1)
+    y, _, _ = ops.conv2d(nhwc(a), hwio(wt), 3, 1, 1, src1=nhwc(skip), mode0=1)
+    assert rel_err(to_nchw(y), ref) < 2e-6
+    # split outputs at channel 64 + accumulate into out0
+    base = torch.randn((B, 2 * h, 2 * w_, 64), generator=g).to(DEV)
+    o0, o1, _ = ops.conv2d(nhwc(a), hwio(wt), 3, 1, 1, src1=nhwc(skip), mode0=1, split=64, out0=base.clone(),
+                           accumulate=True)
+    assert rel_err(to_nchw(o0), ref[:, :64] + to_nchw(base)) < 2e-6
+    assert rel_err(to_nchw(o1), ref[:, 64:]) < 2e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,k,p", [(64, 128, 3, 1), (64, 128, 1, 0)])
+def test_conv_dgrad_stride2_via_zero_insert(Cin, Cout, k, p):
+    """data gradient of a stride-2 conv = stride-1 conv over the zero-inserted dy with flipped/transposed w."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 16, 24
+    x = torch.randn((B, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn((Cout, Cin, k, k), generator=g, dtype=torch.float64) * 0.05
+    y = F.conv2d(x, wt, stride=2, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    wd = ops.weight_flip_transpose(hwio(wt))
+    dx, _, _ = ops.conv2d(nhwc(dy), wd, k, 1, k - 1 - p, mode0=2)
+    assert rel_err(to_nchw(dx), x.grad) < 2e-6
+
+
+def test_conv_dgrad_stride1():
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    B, H, W, Cin, Cout = 2, 16, 16, 32, 64
+    x = torch.randn((B, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn((Cout, Cin, 3, 3), generator=g, dtype=torch.float64) * 0.05
+    y = F.conv2d(x, wt, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dx, _, _ = ops.conv2d(nhwc(dy), ops.weight_flip_transpose(hwio(wt)), 3, 1, 1)
+    assert rel_err(to_nchw(dx), x.grad) < 2e-6
+
+
+WGRAD_CASES = [
+    (2, 32, 32, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 256, 3, 1, 1),
+    (1, 40, 24, 16, 16, 3, 1, 1),
+    (2, 32, 64, 32, 16, 3, 1, 1),
+    (2, 8, 8, 64, 32, 3, 1, 1),
+    (2, 4, 4, 32, 128, 3, 1, 1),
+    (2, 32, 32, 64, 128, 3, 2, 1),
+    (2, 32, 32, 64, 128, 1, 2, 0),
+    (2, 64, 96, 3, 64, 7, 2, 3),
+    (1, 32, 32, 4, 64, 7, 2, 3),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", WGRAD_CASES)
+def test_conv_wgrad(B, H, W, Cin, Cout, k, s, p):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H + Cin * 7 + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g, dtype=torch.float64)
+    wt = (torch.randn((Cout, Cin, k, k), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dw = ops.conv2d_wgrad(nhwc(x), nhwc(dy), k, s, p)
+    got = dw.detach().cpu().permute(3, 2, 0, 1).double()   # HWIO -> OIHW
+    assert rel_err(got, wt.grad) < 3e-6
+
+
+def test_conv_wgrad_upsample_concat():
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    B, h, w_, C0, C1, Cout = 2, 8, 8, 64, 64, 32
+    a = torch.randn((B, C0, h, w_), generator=g, dtype=torch.float64)
+    skip = torch.randn((B, C1, 2 * h, 2 * w_), generator=g, dtype=torch.float64)
+    wt = (torch.randn((Cout, C0 + C1, 3, 3), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(torch.cat([F.interpolate(a, scale_factor=2, mode="nearest"), skip], 1), wt, padding=1)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dw = ops.conv2d_wgrad(nhwc(a), nhwc(dy), 3, 1, 1, src1=nhwc(skip), mode0=1)
+    assert rel_err(dw.cpu().permute(3, 2, 0, 1), wt.grad) < 3e-6
+
+
+@pytest.mark.parametrize("C,shape", [(64, (2, 16, 16)), (16, (3, 40, 24)), (512, (2, 2, 2))])
+def test_batchnorm_train_forward_backward(C, shape):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    B, H, W = shape
+    y = (torch.randn((B, C, H, W), generator=g, dtype=torch.float64) * 1.5 + 0.3).requires_grad_(True)
+    res = torch.randn((B, C, H, W), generator=g, dtype=torch.float64)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    rm = torch.zeros(C, dtype=torch.float64)
+    rv = torch.ones(C, dtype=torch.float64)
+    out = F.relu(F.batch_norm(y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5) + res)
+    dout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dout)
+    # HIP: statistics from the conv epilogue are emulated with a 1x1 identity... use torch sums as the partials
+    yg = nhwc(y.detach())
+    stats = torch.stack([yg.sum(dim=(0, 1, 2)), (yg * yg).sum(dim=(0, 1, 2))]).reshape(2, 1, C).contiguous()
+    rmg, rvg = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd, scale, shift = ops.bn_finalize(stats, B * H * W, gamma.detach().float().to(DEV),
+                                                 beta.detach().float().to(DEV), rmg, rvg)
+    z = ops.bn_act(yg, scale, shift, res=nhwc(res), relu=True)
+    assert rel_err(to_nchw(z), out.detach()) < 1e-5
+    np.testing.assert_allclose(rmg.cpu().double(), rm, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rvg.cpu().double(), rv, rtol=1e-5, atol=1e-6)
+    dy, dgamma, dbeta, dres = ops.bn_backward(nhwc(dout), z, yg, mean, invstd, gamma.detach().float().to(DEV),
+                                              want_dres=True)
+    assert rel_err(to_nchw(dy), y.grad) < 2e-5
+    assert rel_err(dgamma.cpu(), gamma.grad) < 2e-5
+    assert rel_err(dbeta.cpu(), beta.grad) < 2e-5
+    assert rel_err(to_nchw(dres), dout * (out.detach() > 0)) < 1e-6
+
+
+def test_maxpool_forward_backward_with_ties():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 64, 20, 28
+    x = F.relu(torch.randn((B, C, H, W), generator=g)).double()   # many exact zeros -> ties
+    x.requires_grad_(True)
+    out = F.max_pool2d(x, 3, 2, 1)
+    dout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dout)
+    o, am = ops.maxpool3x3s2(nhwc(x.detach()))
+    assert torch.equal(to_nchw(o), out.detach().float().double())
+    dx = ops.maxpool3x3s2_bwd(nhwc(dout), am, H, W)
+    assert rel_err(to_nchw(dx), x.grad) < 1e-6
+
+
+def test_upsample_bwd_and_layout():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn((2, 32, 6, 10), generator=g, dtype=torch.float64, requires_grad=True)
+    up = F.interpolate(a, scale_factor=2, mode="nearest")
+    dup = torch.randn(up.shape, generator=g, dtype=torch.float64)
+    up.backward(dup)
+    assert rel_err(to_nchw(ops.upsample2x_bwd(nhwc(dup))), a.grad) < 1e-6
+    x = torch.randn((3, 3, 8, 16), generator=g)
+    assert torch.equal(ops.nchw_to_nhwc(x.to(DEV)).cpu(), x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.to(DEV))).cpu(), x)
+
+
+@pytest.mark.parametrize("K", [2, 3])
+def test_head_forward_backward(K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(K)
+    B, H, W, Cin = 2, 24, 40, 16
+    x = torch.randn((B, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn((K, Cin, 3, 3), generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = (torch.randn(K, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    ref = F.conv2d(x, w, b, padding=1)
+    dl = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dl)
+    w_ohwi = w.detach().permute(0, 2, 3, 1).contiguous().float().to(DEV)
+    logits, am = ops.head_fwd(nhwc(x.detach()), w_ohwi, b.detach().float().to(DEV), argmax="int64")
+    assert rel_err(logits.cpu(), ref.detach()) < 2e-6
+    assert torch.equal(am.cpu(), logits.cpu().argmax(dim=1))
+    dx, dw, db = ops.head_bwd(nhwc(x.detach()), w_ohwi, dl.float().to(DEV))
+    assert rel_err(to_nchw(dx), x.grad) < 2e-6
+    assert rel_err(dw.cpu().permute(0, 3, 1, 2), w.grad) < 1e-5
+    assert rel_err(db.cpu(), b.grad) < 1e-5
+
+
+def test_flat_adam_matches_torch():
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    n = 100_003
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=3e-4)
+    pg = p0.clone().to(DEV)
+    fa = ops.FlatAdam(pg, lr=3e-4, max_norm=0.5)
+    for step in range(3):
+        grad = torch.randn(n, generator=g) * (0.001 if step == 1 else 1.0)   # step 1: below the clip norm
+        ref_p.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
+        opt.step()
+        norm = fa.step(grad.to(DEV))
+        assert float(norm) == pytest.approx(float(grad.norm()), rel=1e-5)
+    assert rel_err(pg.cpu(), ref_p.detach()) < 1e-6

@@ -1,0 +1,150 @@
+"""End-to-end parity of the HIP U-Net + fused losses against the CPU oracle (oracle/).  Needs an MI355X.
+
+Tolerances: logits max-abs error <= 1e-4 * max|logit| (fp32, different summation order
+than oneDNN), argmax maps bit-identical except where the top-2 logit margin is below that error bound,
+losses rel 1e-5, parameter gradients rel-L2 <= 1e-4 per tensor (small tensors: 1e-3 of global scale).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pair(in_ch=3, classes=2, seed=0):
+    from deadtrees_amd.network.unet import UNetHIP
+    from oracle.unet_ref import make_oracle
+    ref = make_oracle(in_ch, classes, seed=seed)
+    m = UNetHIP(in_channels=in_ch, classes=classes)
+    m.load_state_dict(ref.state_dict())
+    return ref, m.to(DEV)
+
+
+def _synth(B, H, W, C=3, K=2, seed=1234):
+    from deadtrees_amd.data.synthetic import synth_batch
+    return synth_batch(B, H, W, C, K, seed)
+
+
+def test_state_dict_roundtrip_on_device():
+    ref, m = _pair()
+    sd_ref, sd = ref.state_dict(), m.state_dict()
+    assert set(sd_ref.keys()) == set(sd.keys())
+    for k in sd_ref:
+        assert torch.equal(sd_ref[k].cpu(), sd[k].cpu()), k
+
+
+@pytest.mark.parametrize("B,H,W,C,K", [(2, 64, 64, 3, 2), (1, 256, 256, 3, 2), (2, 96, 160, 4, 3)])
+def test_forward_eval_parity_and_argmax(B, H, W, C, K):
+    ref, m = _pair(C, K)
+    img, _ = _synth(B, H, W, C, K)
+    ref.eval()
+    m.eval()
+    with torch.no_grad():
+        want = ref(img)
+        want64 = ref.double()(img.double())
+        got = m(img.to(DEV)).cpu()
+    scale = float(want64.abs().max())
+    err = float((got.double() - want64).abs().max())
+    err_ref = float((want.double() - want64).abs().max())
+    assert err <= 1e-4 * scale, (err, err_ref, scale)
+    # argmax: identical wherever the fp64 top-2 margin exceeds the error bound of either side
+    top2 = want64.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    safe = margin > 4 * max(err, err_ref)
+    am_hip = m.predict_classes(img.to(DEV)).cpu()
+    assert am_hip.dtype == torch.int64 and tuple(am_hip.shape) == (B, H, W)
+    assert torch.equal(am_hip, got.argmax(dim=1))           # fused argmax == argmax of its own logits
+    assert torch.equal(am_hip[safe], want64.argmax(dim=1)[safe])
+    flips = int((am_hip != want.argmax(dim=1)).sum())
+    assert flips <= int((~safe).sum())
+    assert float(safe.float().mean()) > 0.99
+
+
+def test_train_step_gradient_parity():
+    from deadtrees_amd.loss.seg_loss import seg_loss
+    from oracle.train_ref import loss_from_logits
+    B, H, W = 2, 64, 64
+    ref, m = _pair()
+    img, mask = _synth(B, H, W)
+    ref.train()
+    m.train()
+    logits_ref = ref(img)
+    loss_ref, _ = loss_from_logits(logits_ref, mask, ("GDICE", "FOCAL"))
+    loss_ref.backward()
+    logits = m(img.to(DEV))
+    loss, parts, err = seg_loss(logits, mask.to(DEV), None, ("GDICE", "FOCAL"))
+    loss.backward()
+    assert int(err) == 0
+    assert float((logits.detach().cpu() - logits_ref.detach()).abs().max()) <= 2e-4 * float(logits_ref.abs().max())
+    assert float(loss) == pytest.approx(float(loss_ref), rel=2e-5)
+    grads = m.smp_grad_dict()
+    gref = {k: p.grad for k, p in ref.named_parameters()}
+    assert set(grads.keys()) == set(gref.keys())
+    gscale = max(float(g.abs().max()) for g in gref.values())
+    worst = ("", 0.0)
+    for k, gr in gref.items():
+        g = grads[k]
+        rel = float((g.double() - gr.double()).norm() / (gr.double().norm() + 1e-3 * gscale * gr.numel() ** 0.5))
+        if rel > worst[1]:
+            worst = (k, rel)
+    assert worst[1] < 1e-3, worst
+    # BN running statistics were updated like torch's
+    sd_ref, sd = ref.state_dict(), m.state_dict()
+    for k in sd_ref:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), sd_ref[k].numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(sd_ref[k]) == 1
+    # flat .grad delivered through autograd equals the engine's buffer
+    assert torch.equal(m.flat_params.grad, m._grad_buffer())
+
+
+CASES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "losses_*.npz")))
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
+def test_fused_losses_vs_reference_golden(path):
+    """values and d(loss)/d(logits) against vectors produced by the imported reference losses."""
+    from deadtrees_amd.loss.seg_loss import seg_loss
+    z = np.load(path)
+    mask = torch.from_numpy(z["mask"]).to(DEV)
+    dist = torch.from_numpy(z["distmap"]).to(DEV)
+    for combo in ("GDICE+FOCAL", "DICE+FOCAL", "GDICE+BOUNDARY+FOCAL"):
+        names = tuple(combo.split("+"))
+        lg = torch.from_numpy(z["logits"]).to(DEV).requires_grad_(True)
+        total, parts, err = seg_loss(lg, mask, dist if "BOUNDARY" in names else None, names)
+        total.backward()
+        assert int(err) == 0
+        assert float(total) == pytest.approx(float(z[f"loss[{combo}]"]), rel=1e-5, abs=1e-6)
+        ref = z[f"dlogits[{combo}]"]
+        np.testing.assert_allclose(lg.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max() + 1e-10)
+        if "GDICE" in names:
+            assert float(parts["dice_loss"]) == pytest.approx(float(z["gdice"]), rel=1e-5, abs=1e-6)
+        else:
+            assert float(parts["dice_loss"]) == pytest.approx(float(z["dice"]), rel=1e-5, abs=1e-6)
+        assert float(parts["focal_loss"]) == pytest.approx(float(z["focal"]), rel=1e-5, abs=1e-6)
+        assert float(parts["ce_loss"]) == pytest.approx(float(z["ce"]), rel=1e-5, abs=1e-6)
+        if "BOUNDARY" in names:
+            assert float(parts["boundary_loss"]) == pytest.approx(float(z["boundary"]), rel=1e-5, abs=1e-5)
+
+
+def test_fscore_matches_oracle_and_label_error_flag():
+    from deadtrees_amd.loss.seg_loss import seg_loss
+    from oracle import losses_ref as L
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn((3, 3, 32, 32), generator=g) * 3
+    mask = torch.randint(0, 3, (3, 32, 32), generator=g)
+    _, parts, err = seg_loss(logits.to(DEV), mask.to(DEV), None, ("GDICE",))
+    p = logits.softmax(1)
+    assert float(parts["dice"]) == pytest.approx(float(L.fscore(p, mask, ignore_channels=(0,))), rel=1e-6)
+    assert float(parts["dice_with_bg"]) == pytest.approx(float(L.fscore(p, mask)), rel=1e-6)
+    assert int(err) == 0
+    bad = mask.clone()
+    bad[0, 0, 0] = 7
+    _, _, err = seg_loss(logits.to(DEV), bad.to(DEV), None, ("GDICE",))
+    assert int(err) == 1
