@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py — 512x512 RGB tiles/s of the U-Net training step (fwd + loss + bwd + clip + Adam) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, RCCL).
+Rank 0 prints ONE JSON line.  Workload = BASELINE.json configs[1]: reference U-Net (smp Unet/resnet34
+topology), fp32, batch 32 per GPU, 512x512x3 synthetic tiles, losses GDICE+FOCAL, clip 0.5, Adam 3e-4.
+
+`roofline`: the dominant kernel (most GPU time among the convolution launches) timed live with HIP
+events on the launch stream; achieved = algorithmic conv FLOPs of those launches / their summed
+duration; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  The whole fp32 network is
+compute-bound (176 FLOP/B), so the binding roof is "mfma"; the HBM fraction of the step is reported
+next to it in `hbm_frac_step`.
+`cpu_baseline`: the oracle port of the reference's CPU path (oracle/train_ref.py) timed on this box's host
+cores on a bounded sample (B=2, 512x512, a few steps) — rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_TILE_TRAIN = 186.53e9      # SURVEY §8d / BASELINE.md §2 (conv FLOPs fwd+bwd, 512x512x3, K=2)
+BYTES_PER_TILE_TRAIN = 924.3e6      # ideal-fused fp32 algorithmic HBM bytes per tile
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback on the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.trainer import HipTrainer
+
+    B, S = args.batch, args.size
+    model = UNetHIP(in_channels=3, classes=2)
+    model.reset_parameters(seed=0)
+    model.to(dev)
+    tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed)
+    tr.broadcast_parameters(0)
+    img, mask = synth_batch(B, S, S, 3, 2, seed=1234 + rank)
+    img, mask = img.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
+
+    def sync():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(img, mask)
+    sync()
+    prof = []
+    model.engine.profile = prof
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        loss = tr.step(img, mask)
+    e1.record()
+    sync()
+    wall = time.perf_counter() - t0
+    model.engine.profile = None
+    dt = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    wall = float(dt)
+    tiles = B * world * args.steps
+    value = tiles / wall
+    ms_per_step = 1e3 * wall / args.steps
+
+    # ---- roofline of the dominant conv kernel (rank 0's launches)
+    agg = {}
+    for name, flops, a, b in prof:
+        t = a.elapsed_time(b) * 1e-3
+        r = agg.setdefault(name, [0.0, 0.0, 0])
+        r[0] += t
+        r[1] += flops
+        r[2] += 1
+    roof = None
+    conv_time = sum(r[0] for r in agg.values())
+    if agg:
+        name, (t, fl, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        ach = fl / t / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
+                "share_of_step": round(t / (float(e0.elapsed_time(e1)) * 1e-3), 4)}
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                roof["traffic"] = json.load(open(tfile)).get(name)
+            except Exception:
+                pass
+    per_gpu_tiles_s = B * args.steps / wall
+    out = {
+        "metric": "512x512 RGB tiles/sec (train fwd+bwd)", "value": round(value, 2), "unit": "tiles/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: reference U-Net (smp Unet/resnet34 topology) fp32 train step, "
+                               f"batch {B}/GPU, {S}x{S}x3 tiles, GDICE+FOCAL, clip 0.5, Adam 3e-4",
+                   "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
+        "loss": round(float(loss), 6),
+        "whole_net": {"tflops": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12, 2),
+                      "mfma_frac": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12 / PEAK_FP32_TFLOPS, 4),
+                      "hbm_frac_step": round(per_gpu_tiles_s * BYTES_PER_TILE_TRAIN / 1e9 / PEAK_HBM_GBS, 4),
+                      "conv_fwd_dgrad_share_of_step": round(conv_time / (float(e0.elapsed_time(e1)) * 1e-3), 4)},
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.train_ref import time_cpu_baseline
+        cimg, cmask = synth_batch(2, S, S, 3, 2, seed=1234)
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        res = time_cpu_baseline(cimg, cmask, steps=args.cpu_steps, warmup=1, threads=cores)
+        out["cpu_baseline"] = {"value": round(res["tiles_per_s"], 3), "unit": "tiles/s", "cores": res["threads"],
+                               "kind": "port",
+                               "sample": f"oracle port of the reference CPU path (torch {torch.__version__} CPU, "
+                                         f"B=2, {S}x{S}, {args.cpu_steps} timed steps after 1 warm-up, median)"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -382,3 +382,14 @@ extern "C" int dt_weight_flip_transpose(const float* w, float* wd, int ksize, in
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
+
+// which kernel instantiation dt_conv2d launches for a descriptor (profiling / roofline attribution)
+extern "C" int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck) {
+  int rc = validate(d);
+  if (rc != DT_OK) return rc;
+  ConvCfg c = pick_cfg(d);
+  if (tw) *tw = c.tw;
+  if (tn) *tn = d->ksize == 7 ? 64 : c.tn;
+  if (ck) *ck = d->ksize == 7 ? 4 : ((d->ksize == 3 && d->stride == 2) ? 8 : 16);
+  return DT_OK;
+}

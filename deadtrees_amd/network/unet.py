@@ -51,6 +51,8 @@ class UNetEngine:
         self._ws = {}
         self.saved: Optional[_Saved] = None
         self.grad_hook: Optional[Callable[[str, int, int], None]] = None
+        # when a list: every dt_conv2d launch appends (kernel name, algorithmic FLOPs, start, end events)
+        self.profile: Optional[list] = None
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, name: str, numel: int, dtype=torch.float32, device=None) -> torch.Tensor:
@@ -63,9 +65,25 @@ class UNetEngine:
     def _desc(self, B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split=0, acc=0):
         return _lib.ConvDesc(B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split, acc)
 
+    def _conv_kernel_name(self, desc) -> str:
+        tw, tn, ck = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.lib.dt_conv2d_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck)), "dt_conv2d_config")
+        return f"conv_fwd_kernel<{desc.ksize},{desc.stride},{tw.value},{tn.value},{ck.value}>"
+
     def _conv(self, desc, src0, src1, w, out0, out1=None, stats=None):
+        prof = self.profile
+        if prof is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(self.lib.dt_conv2d(C.byref(desc), _p(src0), _p(src1), _p(w), _p(out0), _p(out1), _p(stats),
                                       _stream()), "dt_conv2d")
+        if prof is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            flops = 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout * desc.Ho * desc.Wo * desc.B
+            if desc.mode0 == 2:
+                flops /= 4.0   # transposed conv: 3/4 of the zero-inserted input does no algorithmic work
+            prof.append((self._conv_kernel_name(desc), flops, e0, e1))
 
     # ------------------------------------------------------------------ forward units
     def _conv_bn(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, training):

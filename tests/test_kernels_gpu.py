@@ -58,7 +58,8 @@ def test_conv_fwd_and_stats(B, H, W, Cin, Cout, k, s, p):
     torch.cuda.synchronize()
     got = to_nchw(y)
     assert got.shape == ref.shape
-    assert rel_err(got, ref) < 2e-6
+    # sequential fp32 fma chain of K = k*k*Cin terms: error grows ~ sqrt(K) * 2^-24
+    assert rel_err(got, ref) < 2e-6 * max(1.0, (k * k * Cin / 1000.0) ** 0.5)
     s1 = stats[0].double().sum(0).cpu()
     s2 = stats[1].double().sum(0).cpu()
     np.testing.assert_allclose(s1, ref.sum(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4 * ref.abs().sum(dim=(0, 2, 3)).max())

@@ -66,33 +66,50 @@ def test_forward_eval_parity_and_argmax(B, H, W, C, K):
 
 
 def test_train_step_gradient_parity():
+    """loss + every parameter gradient of one training step vs the oracle.
+
+    End-to-end gradients of a ReLU/max-pool network are ill-conditioned in fp32 (an activation within
+    rounding distance of zero flips its mask), so the yardstick is the fp64 oracle: the HIP result must
+    be as close to it as the fp32 CPU oracle is (factor 3), tensor by tensor.  Exact per-kernel backward
+    parity is covered in tests/test_kernels_gpu.py."""
+    import copy
     from deadtrees_amd.loss.seg_loss import seg_loss
     from oracle.train_ref import loss_from_logits
-    B, H, W = 2, 64, 64
+    B, H, W = 2, 128, 128
     ref, m = _pair()
+    ref64 = copy.deepcopy(ref).double()
     img, mask = _synth(B, H, W)
     ref.train()
+    ref64.train()
     m.train()
     logits_ref = ref(img)
     loss_ref, _ = loss_from_logits(logits_ref, mask, ("GDICE", "FOCAL"))
     loss_ref.backward()
+    logits64 = ref64(img.double())
+    loss64, _ = loss_from_logits(logits64, mask, ("GDICE", "FOCAL"))
+    loss64.backward()
     logits = m(img.to(DEV))
     loss, parts, err = seg_loss(logits, mask.to(DEV), None, ("GDICE", "FOCAL"))
     loss.backward()
     assert int(err) == 0
-    assert float((logits.detach().cpu() - logits_ref.detach()).abs().max()) <= 2e-4 * float(logits_ref.abs().max())
-    assert float(loss) == pytest.approx(float(loss_ref), rel=2e-5)
+    e_hip = float((logits.detach().cpu().double() - logits64.detach()).abs().max())
+    e_ref = float((logits_ref.detach().double() - logits64.detach()).abs().max())
+    assert e_hip <= max(3 * e_ref, 1e-4 * float(logits64.detach().abs().max())), (e_hip, e_ref)
+    assert float(loss.detach()) == pytest.approx(float(loss64.detach()), rel=2e-5)
     grads = m.smp_grad_dict()
-    gref = {k: p.grad for k, p in ref.named_parameters()}
-    assert set(grads.keys()) == set(gref.keys())
-    gscale = max(float(g.abs().max()) for g in gref.values())
-    worst = ("", 0.0)
-    for k, gr in gref.items():
-        g = grads[k]
-        rel = float((g.double() - gr.double()).norm() / (gr.double().norm() + 1e-3 * gscale * gr.numel() ** 0.5))
-        if rel > worst[1]:
-            worst = (k, rel)
-    assert worst[1] < 1e-3, worst
+    g32 = {k: p.grad for k, p in ref.named_parameters()}
+    g64 = {k: p.grad for k, p in ref64.named_parameters()}
+    assert set(grads.keys()) == set(g64.keys())
+    tot_hip = tot_ref = tot = 0.0
+    for k, g in g64.items():
+        n = float(g.norm()) + 1e-30
+        eh = float((grads[k].double() - g).norm())
+        er = float((g32[k].double() - g).norm())
+        assert eh <= 3.0 * er + 1e-4 * n, (k, eh / n, er / n)
+        tot_hip += eh ** 2
+        tot_ref += er ** 2
+        tot += n ** 2
+    assert tot_hip ** 0.5 <= 2.0 * tot_ref ** 0.5 + 1e-5 * tot ** 0.5, (tot_hip, tot_ref, tot)
     # BN running statistics were updated like torch's
     sd_ref, sd = ref.state_dict(), m.state_dict()
     for k in sd_ref:
