@@ -145,6 +145,7 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        cores = min(cores, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
         res = time_cpu_baseline(cimg, cmask, steps=args.cpu_steps, warmup=1, threads=cores)
         out["cpu_baseline"] = {"value": round(res["tiles_per_s"], 3), "unit": "tiles/s", "cores": res["threads"],
                                "kind": "port",

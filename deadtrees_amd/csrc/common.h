@@ -42,3 +42,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---- shared two-stage column reduction (elementwise.hip): in [planes][P][N] -> out [planes][ceil(P/RB)][N]
+// rows_per_block RB; N % 4 == 0; fp32 partial sums in a fixed order (deterministic).
+int dt_reduce_rows_launch(const float* in, float* out, int planes, int P, int N, int RB, hipStream_t st);
+static inline int dt_reduce_rows_out(int P, int RB) { return (P + RB - 1) / RB; }

@@ -134,8 +134,32 @@ __device__ __forceinline__ void fill_weights(float* __restrict__ lds_w, const fl
   }
 }
 
+// all KS*KS taps x CK input channels of one staged chunk on the matrix cores
+template <int KS, int TN, int CK, int PLANE, int HALO_W>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ lds_in, const float* __restrict__ lds_w,
+                                          const int (&abase)[2], int bbase, f32x16 (&acc)[2][TN / 32]) {
+  constexpr int NT = TN / 32;
+#pragma unroll
+  for (int tap = 0; tap < KS * KS; ++tap) {
+    const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+    for (int kk = 0; kk < CK / 2; ++kk) {
+      float av[2], bv[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) av[mt] = lds_in[abase[mt] + 2 * kk * PLANE + kh * HALO_W + kw];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = lds_w[bbase + (tap * CK + 2 * kk) * TN + 32 * j];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[j], acc[mt][j], 0, 0, 0);
+    }
+  }
+}
+
 template <int KS, int STRIDE, int TW, int TN, int CK>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
   using G = ConvGeom<KS, STRIDE, TW, CK>;
   constexpr int NT = TN / 32;
   constexpr int IN_ELEMS = CK * G::PLANE;
@@ -175,27 +199,95 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvArgs a) {
       for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
 
   const int Cin = a.C0 + a.C1;
-  for (int c0 = 0; c0 < Cin; c0 += CK) {
-    __syncthreads();
-    fill_input_planar<KS, STRIDE, TW, CK>(lds_in, a, b, iy0, ix0, c0);
-    fill_weights<G::TAPS, CK, TN>(lds_w, a.w, Cin, a.Cout, c0, n0);
-    __syncthreads();
+  if constexpr (KS == 7) {
+    // stem (Cin = 3/4: scalar staging, a single chunk): synchronous fill
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+      __syncthreads();
+      fill_input_planar<KS, STRIDE, TW, CK>(lds_in, a, b, iy0, ix0, c0);
+      fill_weights<G::TAPS, CK, TN>(lds_w, a.w, Cin, a.Cout, c0, n0);
+      __syncthreads();
+      mma_chunk<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
+    }
+  } else {
+    // Software-pipelined staging: the global loads of chunk c+1 are issued (into registers) before the
+    // MFMAs of chunk c and written to LDS after them, so HBM/L2 latency hides under the matrix work.
+    constexpr int QI = CK / 4;                       // float4 per pixel
+    constexpr int IN_TOTAL = G::HALO_H * G::HALO_W * QI;
+    constexpr int IN_IT = (IN_TOTAL + 255) / 256;
+    constexpr int QW = TN / 4;
+    constexpr int W_TOTAL = G::TAPS * CK * QW;
+    constexpr int W_IT = (W_TOTAL + 255) / 256;
+    static_assert(256 % QI == 0 && 256 % QW == 0, "lane->quad mapping must be iteration invariant");
+    const int tid = threadIdx.x;
+    const int qi = tid % QI, pix0 = tid / QI;
+    const int qw = tid % QW, row0 = tid / QW;
+    int pidx0[IN_IT], pidx1[IN_IT];   // pixel index in source 0 / source 1, -1 = zero (padding / inserted zero)
+    const int Hs0 = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.mode0 ? (a.Win >> 1) : a.Win;
 #pragma unroll
-    for (int tap = 0; tap < G::TAPS; ++tap) {
-      const int kh = tap / KS, kw = tap % KS;
+    for (int it = 0; it < IN_IT; ++it) {
+      const int pix = pix0 + it * (256 / QI);
+      const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
+      const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
+      const bool inb = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && pix < G::HALO_H * G::HALO_W;
+      bool ok0 = inb;
+      if (a.mode0 == 2) ok0 = ok0 && (((iy | ix) & 1) == 0);
+      const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
+      pidx0[it] = ok0 ? (b * Hs0 + sy) * Ws0 + sx : -1;
+      pidx1[it] = inb ? (b * a.Hin + iy) * a.Win + ix : -1;
+    }
+    int woff[W_IT];
 #pragma unroll
-      for (int kk = 0; kk < CK / 2; ++kk) {
-        float av[2], bv[NT];
+    for (int it = 0; it < W_IT; ++it) {
+      const int row = row0 + it * (256 / QW);
+      const int tap = row / CK, k = row - tap * CK;
+      woff[it] = (row < G::TAPS * CK && n0 + 4 * qw < a.Cout) ? (tap * Cin + k) * a.Cout + n0 + 4 * qw : -1;
+    }
+    f32x4 rin[IN_IT], rw[W_IT];
+    auto issue_loads = [&](int c0) {
+      const bool use0 = c0 < a.C0;
+      const float* src = use0 ? a.src0 : a.src1;
+      const int C = use0 ? a.C0 : a.C1;
+      const int cc = (use0 ? c0 : c0 - a.C0) + 4 * qi;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) av[mt] = lds_in[abase[mt] + 2 * kk * G::PLANE + kh * G::HALO_W + kw];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = lds_w[bbase + (tap * CK + 2 * kk) * TN + 32 * j];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[j], acc[mt][j], 0, 0, 0);
+      for (int it = 0; it < IN_IT; ++it) {
+        const int p = use0 ? pidx0[it] : pidx1[it];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p >= 0 && cc < C) v = *reinterpret_cast<const f32x4*>(src + (size_t)p * C + cc);
+        rin[it] = v;
       }
+#pragma unroll
+      for (int it = 0; it < W_IT; ++it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int k = (row0 + it * (256 / QW)) % CK;
+        if (woff[it] >= 0 && c0 + k < Cin) v = *reinterpret_cast<const f32x4*>(a.w + (size_t)c0 * a.Cout + woff[it]);
+        rw[it] = v;
+      }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+      for (int it = 0; it < IN_IT; ++it) {
+        const int pix = pix0 + it * (256 / QI);
+        if (IN_TOTAL % 256 == 0 || pix < G::HALO_H * G::HALO_W) {
+          float* d = lds_in + (4 * qi) * G::PLANE + pix;
+          d[0] = rin[it][0];
+          d[G::PLANE] = rin[it][1];
+          d[2 * G::PLANE] = rin[it][2];
+          d[3 * G::PLANE] = rin[it][3];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < W_IT; ++it) {
+        const int row = row0 + it * (256 / QW);
+        if (W_TOTAL % 256 == 0 || row < G::TAPS * CK) *reinterpret_cast<f32x4*>(lds_w + row * TN + 4 * qw) = rw[it];
+      }
+    };
+    issue_loads(0);
+    for (int c0 = 0; c0 < Cin; c0 += CK) {
+      __syncthreads();   // every wave is done reading the previous chunk
+      write_lds();
+      __syncthreads();
+      if (c0 + CK < Cin) issue_loads(c0 + CK);
+      mma_chunk<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
     }
   }
 

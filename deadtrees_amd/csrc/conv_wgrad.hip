@@ -33,7 +33,7 @@ struct WGeom {
 };
 
 template <int KS, int STRIDE, int TW, int TPX, int WCI, int WCO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   using G = WGeom<KS, STRIDE, TW, TPX>;
   constexpr int WK = 4 / (WCI * WCO);
   constexpr int CIW = WCI * 32, COW = WCO * 32;
@@ -65,58 +65,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  for (int tile = ks; tile < a.T; tile += a.ksplit) {
+  // Software-pipelined staging (same scheme as conv_fwd): the global loads of the next pixel tile are in
+  // flight, in registers, while the matrix cores work on the current one.
+  constexpr int QX = CIW / 4, QY = COW / 4;
+  constexpr int X_TOTAL = G::HALO_H * G::HALO_W * QX, X_IT = (X_TOTAL + 255) / 256;
+  constexpr int Y_TOTAL = TPX * QY, Y_IT = (Y_TOTAL + 255) / 256;
+  static_assert(256 % QX == 0 && 256 % QY == 0, "lane->quad mapping must be iteration invariant");
+  const int qx = tid % QX, px0 = tid / QX;
+  const int qy = tid % QY, py0 = tid / QY;
+  // channel quad of x handled by this lane: source select is tile invariant
+  const int cx = ci0 + 4 * qx;
+  const bool x_use0 = cx < a.C0;
+  const float* xsrc = x_use0 ? a.src0 : a.src1;
+  const int xC = x_use0 ? a.C0 : a.C1;
+  const int xcc = x_use0 ? cx : cx - a.C0;
+  const int xmode = x_use0 ? a.mode0 : 0;
+  const int xHs = xmode ? (a.Hin >> 1) : a.Hin, xWs = xmode ? (a.Win >> 1) : a.Win;
+  const bool x_ch_ok = cx < Cin;
+  const int cy = co0 + 4 * qy;
+  const bool y_ch_ok = cy < a.Cout;
+  f32x4 rx[X_IT], ry[Y_IT];
+  auto issue_loads = [&](int tile) {
     const int tx = tile % a.tiles_x;
     const int ty = (tile / a.tiles_x) % a.tiles_y;
     const int b = tile / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * G::TH, ox0 = tx * TW;
     const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
-    __syncthreads();
-    // ---- stage x halo tile: [halo pixel][CIW]
-    {
-      constexpr int Q = CIW / 4;
-      constexpr int TOTAL = G::HALO_H * G::HALO_W * Q;
-      for (int idx = tid; idx < TOTAL; idx += 256) {
-        const int q = idx % Q, pix = idx / Q;
-        const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
-        const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
-        const int c = ci0 + 4 * q;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && c < Cin) {
-          const float* src;
-          int C, cc, mode;
-          if (c < a.C0) {
-            src = a.src0; C = a.C0; cc = c; mode = a.mode0;
-          } else {
-            src = a.src1; C = a.C1; cc = c - a.C0; mode = 0;
-          }
-          bool ok = true;
-          if (mode == 2) ok = (((iy | ix) & 1) == 0);
-          if (ok) {
-            const int Hs = mode ? (a.Hin >> 1) : a.Hin, Ws = mode ? (a.Win >> 1) : a.Win;
-            const int sy = mode ? (iy >> 1) : iy, sx = mode ? (ix >> 1) : ix;
-            v = *reinterpret_cast<const f32x4*>(src + (((size_t)b * Hs + sy) * Ws + sx) * C + cc);
-          }
-        }
-        *reinterpret_cast<f32x4*>(lx + pix * CIW + 4 * q) = v;
-      }
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int pix = px0 + it * (256 / QX);
+      const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
+      const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
+      bool ok = x_ch_ok && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win &&
+                (X_TOTAL % 256 == 0 || pix < G::HALO_H * G::HALO_W);
+      if (xmode == 2) ok = ok && (((iy | ix) & 1) == 0);
+      const int sy = xmode ? (iy >> 1) : iy, sx = xmode ? (ix >> 1) : ix;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(xsrc + (((size_t)b * xHs + sy) * xWs + sx) * xC + xcc);
+      rx[it] = v;
     }
-    // ---- stage dy tile: [pixel][COW]
-    {
-      constexpr int Q = COW / 4;
-      constexpr int TOTAL = TPX * Q;
-      for (int idx = tid; idx < TOTAL; idx += 256) {
-        const int q = idx % Q, pix = idx / Q;
-        const int py = pix / TW, px = pix % TW;
-        const int oy = oy0 + py, ox = ox0 + px;
-        const int c = co0 + 4 * q;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (oy < a.Ho && ox < a.Wo && c < a.Cout)
-          v = *reinterpret_cast<const f32x4*>(a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + c);
-        *reinterpret_cast<f32x4*>(ly + pix * COW + 4 * q) = v;
-      }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int pix = py0 + it * (256 / QY);
+      const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y_ch_ok && oy < a.Ho && ox < a.Wo && (Y_TOTAL % 256 == 0 || pix < TPX))
+        v = *reinterpret_cast<const f32x4*>(a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + cy);
+      ry[it] = v;
     }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int pix = px0 + it * (256 / QX);
+      if (X_TOTAL % 256 == 0 || pix < G::HALO_H * G::HALO_W) *reinterpret_cast<f32x4*>(lx + pix * CIW + 4 * qx) = rx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int pix = py0 + it * (256 / QY);
+      if (Y_TOTAL % 256 == 0 || pix < TPX) *reinterpret_cast<f32x4*>(ly + pix * COW + 4 * qy) = ry[it];
+    }
+  };
+  // register budget: 16*TAPS accumulators + 4 per staged float4; prefetch across the MFMAs only when both fit
+  // in the 256 registers that two waves per SIMD leave each (otherwise: batched loads, then write, then MFMA)
+  constexpr bool PREFETCH = (16 * G::TAPS + 4 * (X_IT + Y_IT)) <= 190;
+  if (PREFETCH && ks < a.T) issue_loads(ks);
+  for (int tile = ks; tile < a.T; tile += a.ksplit) {
     __syncthreads();
+    if (!PREFETCH) issue_loads(tile);
+    write_lds();
+    __syncthreads();
+    if (PREFETCH && tile + a.ksplit < a.T) issue_loads(tile + a.ksplit);
 #pragma unroll
     for (int yy = 0; yy < ROWS; ++yy) {
 #pragma unroll
@@ -162,7 +181,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // 7 kw-taps x 4 channels of a window row 28 consecutive dwords.
 #define STEM_TW 32
 #define STEM_TH 4
-__global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_stem_kernel(const WgradArgs a) {
   constexpr int KS = 7, TW = STEM_TW, TH = STEM_TH;
   constexpr int HALO_H = (TH - 1) * 2 + KS, HALO_W = (TW - 1) * 2 + KS;  // 13 x 69
   constexpr int X_ELEMS = HALO_H * HALO_W * 4 + 32;                       // +32: rows 28..31 read past the end
@@ -238,6 +257,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(const WgradArgs a)
 // ---------------------------------------------------------------- host side
 struct WgCfg {
   int tw, tpx, wci, wco, wk, ksplit, parts, T, tiles_x, tiles_y, ci_blocks, co_blocks;
+  int rb, parts2;  // first reduction stage: blocks of rb slabs -> parts2 slabs (parts2 == parts: single stage)
   bool stem;
 };
 
@@ -281,18 +301,25 @@ static WgCfg wg_cfg(const dt_conv_desc* d) {
   c.tiles_x = dt_cdiv(d->Wo, c.tw);
   c.tiles_y = dt_cdiv(d->Ho, th);
   c.T = d->B * c.tiles_x * c.tiles_y;
-  int ks = 768 / (c.ci_blocks * c.co_blocks);
+  int ks = 512 / (c.ci_blocks * c.co_blocks);
   if (ks < 1) ks = 1;
   if (ks > c.T) ks = c.T;
   c.ksplit = ks;
   c.parts = ks * c.wk;
+  c.rb = 1;
+  c.parts2 = c.parts;
+  if (c.parts > 16) {
+    c.rb = dt_cdiv(c.parts, 16);
+    c.parts2 = dt_cdiv(c.parts, c.rb);
+  }
   return c;
 }
 
 extern "C" size_t dt_conv2d_wgrad_workspace(const dt_conv_desc* d) {
   if (wg_validate(d) != DT_OK) return 0;
   WgCfg c = wg_cfg(d);
-  return (size_t)c.parts * d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout * sizeof(float);
+  const size_t E = (size_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
+  return ((size_t)c.parts + (c.parts2 != c.parts ? c.parts2 : 0)) * E * sizeof(float);
 }
 
 template <int KS, int STRIDE, int TW, int TPX, int WCI, int WCO>
@@ -320,8 +347,8 @@ extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const f
   WgCfg c = wg_cfg(d);
   const int taps = d->ksize * d->ksize;
   const int64_t E = (int64_t)taps * (d->C0 + d->C1) * d->Cout;
-  DT_REQUIRE(workspace_bytes >= (size_t)c.parts * E * sizeof(float), "wgrad: workspace too small (%zu < %zu)",
-             workspace_bytes, (size_t)c.parts * E * sizeof(float));
+  DT_REQUIRE(workspace_bytes >= dt_conv2d_wgrad_workspace(d), "wgrad: workspace too small (%zu < %zu)",
+             workspace_bytes, dt_conv2d_wgrad_workspace(d));
   WgradArgs a;
   a.src0 = src0; a.src1 = src1; a.dy = dy; a.ws = workspace;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
@@ -345,9 +372,18 @@ extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const f
     rc = c.tw == 32 ? wg_dispatch<1, 2, 32>(a, c, grid, st) : wg_dispatch<1, 2, 16>(a, c, grid, st);
   }
   if (rc != DT_OK) return rc;
+  const float* slabs = workspace;
+  int nslabs = c.parts;
+  if (c.parts2 != c.parts) {
+    float* stage = workspace + (size_t)c.parts * E;
+    rc = dt_reduce_rows_launch(workspace, stage, 1, c.parts, (int)E, c.rb, st);
+    if (rc != DT_OK) return rc;
+    slabs = stage;
+    nslabs = c.parts2;
+  }
   int64_t g = (E + 255) / 256;
   if (g > 256 * 8) g = 256 * 8;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, workspace, dw, c.parts, E);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, slabs, dw, nslabs, E);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -8,6 +8,54 @@
 
 #include <math.h>
 
+// ------------------------------------------------------------------ generic row-block reduction
+// in [planes][P][N] -> out [planes][PB][N], PB = ceil(P/RB): block (col-block, row-block, plane) sums RB rows.
+// 256 threads = Q column-quads x (256/Q) row-lanes, 4 independent accumulators per thread for memory-level
+// parallelism, LDS combine across row-lanes in a fixed order.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int P, int N, int RB, int Q) {
+  __shared__ f32x4 sh[256];
+  const int N4 = N >> 2;
+  const int t = threadIdx.x;
+  const int q = t % Q, rl = t / Q, RL = 256 / Q;
+  const int cq = blockIdx.x * Q + q;
+  const int r0 = blockIdx.y * RB;
+  int r1 = r0 + RB;
+  if (r1 > P) r1 = P;
+  const int PB = gridDim.y;
+  const f32x4* src = reinterpret_cast<const f32x4*>(in) + (size_t)blockIdx.z * P * N4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (cq < N4) {
+    int r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+      const f32x4 v0 = src[(size_t)r * N4 + cq];
+      const f32x4 v1 = src[(size_t)(r + RL) * N4 + cq];
+      const f32x4 v2 = src[(size_t)(r + 2 * RL) * N4 + cq];
+      const f32x4 v3 = src[(size_t)(r + 3 * RL) * N4 + cq];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; r < r1; r += RL) a0 += src[(size_t)r * N4 + cq];
+  }
+  sh[t] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && cq < N4) {
+    f32x4 s = sh[q];
+    for (int i = 1; i < RL; ++i) s += sh[i * Q + q];
+    reinterpret_cast<f32x4*>(out)[((size_t)blockIdx.z * PB + blockIdx.y) * N4 + cq] = s;
+  }
+}
+
+int dt_reduce_rows_launch(const float* in, float* out, int planes, int P, int N, int RB, hipStream_t st) {
+  const int N4 = N / 4;
+  int Q = 64;
+  while (Q > N4) Q >>= 1;   // N4 >= 1; Q in {1,2,4,...,64} divides 256
+  if (Q < 1) Q = 1;
+  dim3 grid(dt_cdiv(N4, Q), dt_cdiv(P, RB), planes);
+  hipLaunchKernelGGL(reduce_rows_kernel, grid, dim3(256), 0, st, in, out, P, N, RB, Q);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ BN finalize
 // one workgroup per 16 channels; 256 threads = 16 channels x 16 row-lanes
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int P, int C,
@@ -52,12 +100,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-extern "C" int dt_bn_finalize(const float* stats, int P, int C, double count, const float* gamma,
+#define BN_STAGE1_MIN_ROWS 256
+#define BN_STAGE1_RB 64
+
+extern "C" int64_t dt_bn_stats_floats(int P, int C) {
+  return (int64_t)2 * P * C + (int64_t)2 * dt_reduce_rows_out(P, BN_STAGE1_RB) * C;
+}
+
+extern "C" int dt_bn_finalize(float* stats, int P, int C, double count, const float* gamma,
                               const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* mean, float* invstd, float* scale, float* shift,
                               void* stream) {
   DT_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && P > 0 && C > 0 && count > 0,
              "bn_finalize: bad args");
+  if (P > BN_STAGE1_MIN_ROWS && (C & 3) == 0) {
+    // two-stage: 64-row blocks first (many workgroups), into the scratch tail of the stats buffer
+    const int PB = dt_reduce_rows_out(P, BN_STAGE1_RB);
+    float* scratch = stats + (size_t)2 * P * C;
+    int rc = dt_reduce_rows_launch(stats, scratch, 2, P, C, BN_STAGE1_RB, (hipStream_t)stream);
+    if (rc != DT_OK) return rc;
+    stats = scratch;
+    P = PB;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dt_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, stats, P, C,
                      count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   DT_LAUNCH_CHECK();
@@ -129,83 +193,83 @@ extern "C" int dt_bn_act(const float* y, const float* scale, const float* shift,
 }
 
 // ------------------------------------------------------------------ BN backward
-// pass 1: per-channel partial sums of g and g*xhat.  Workgroup = 256 threads covering a block of
-// ROWS pixels; thread t owns channel-quad (t % C4 within a 256/C4 pixel stripe).
-#define BNB_PIX_PER_WG 1024
+// pass 1: per-channel partial sums of g and g*xhat over blocks of BNB_RB pixels.
+// 256 threads = Q channel-quads x (256/Q) pixel lanes; 2 pixels in flight per thread.
+#define BNB_RB 256
 
 extern "C" int dt_bn_bwd_rows(int64_t n_pix, int C) {
   (void)C;
-  return dt_cdiv(n_pix, BNB_PIX_PER_WG);
+  return dt_cdiv(n_pix, BNB_RB);
 }
+extern "C" int64_t dt_bn_bwd_red_floats(int64_t n_pix, int C) { return dt_bn_stats_floats(dt_bn_bwd_rows(n_pix, C), C); }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dout,
-                                                            const float* __restrict__ out_act,
-                                                            const float* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restrict__ dout,
+                                                            const f32x4* __restrict__ out_act,
+                                                            const f32x4* __restrict__ y,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
-                                                            float* __restrict__ red, int64_t n_pix, int C, int P) {
-  extern __shared__ float sm[];  // [2][rows_per_iter][C]  (rows_per_iter = 1024/C*... see below)
-  const int C4 = C >> 2;
+                                                            float* __restrict__ red, int64_t n_pix, int C4, int Q,
+                                                            int P) {
+  __shared__ f32x4 sh[2][256];
   const int t = threadIdx.x;
-  // threads are laid out as (pixel lane pl, channel quad q): q fastest for coalescing
-  const int lanes_per_pix = C4 < 256 ? C4 : 256;  // C4 <= 256 always holds for C <= 1024
-  const int pix_par = 256 / lanes_per_pix;        // pixels processed concurrently
-  const int q = t % lanes_per_pix, pl = t / lanes_per_pix;
-  const int64_t p0 = (int64_t)blockIdx.x * BNB_PIX_PER_WG;
-  int64_t p1 = p0 + BNB_PIX_PER_WG;
+  const int q = t % Q, rl = t / Q, RL = 256 / Q;
+  const int cq = blockIdx.x * Q + q;
+  const int64_t p0 = (int64_t)blockIdx.y * BNB_RB;
+  int64_t p1 = p0 + BNB_RB;
   if (p1 > n_pix) p1 = n_pix;
-  for (int qq = q; qq < C4; qq += lanes_per_pix) {
-    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[qq];
-    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[qq];
-    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t p = p0 + pl; p < p1; p += pix_par) {
-      const size_t o = (size_t)p * C4 + qq;
-      f32x4 g = reinterpret_cast<const f32x4*>(dout)[o];
-      if (out_act) {
-        const f32x4 a = reinterpret_cast<const f32x4*>(out_act)[o];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
-      }
-      const f32x4 xh = (reinterpret_cast<const f32x4*>(y)[o] - mu) * is;
-      sg += g;
-      sgx += g * xh;
-    }
-    // combine the pix_par pixel-lanes through LDS
-    float* s0 = sm;                       // [pix_par][C]
-    float* s1 = sm + (size_t)pix_par * C;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      s0[(size_t)pl * C + 4 * qq + k] = sg[k];
-      s1[(size_t)pl * C + 4 * qq + k] = sgx[k];
-    }
-    __syncthreads();
-    if (pl == 0) {
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cq];
+  const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cq];
+  f32x4 sg0 = {0.f, 0.f, 0.f, 0.f}, sx0 = sg0, sg1 = sg0, sx1 = sg0;
+  int64_t p = p0 + rl;
+  for (; p + RL < p1; p += 2 * RL) {
+    const size_t o0 = (size_t)p * C4 + cq, o1 = (size_t)(p + RL) * C4 + cq;
+    f32x4 g0 = dout[o0], g1 = dout[o1];
+    const f32x4 y0 = y[o0], y1 = y[o1];
+    if (out_act) {
+      const f32x4 a0 = out_act[o0], a1 = out_act[o1];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float a0 = 0.f, a1 = 0.f;
-        for (int i = 0; i < pix_par; ++i) {
-          a0 += s0[(size_t)i * C + 4 * qq + k];
-          a1 += s1[(size_t)i * C + 4 * qq + k];
-        }
-        red[(size_t)blockIdx.x * C + 4 * qq + k] = a0;
-        red[((size_t)P + blockIdx.x) * C + 4 * qq + k] = a1;
+        g0[k] = a0[k] > 0.f ? g0[k] : 0.f;
+        g1[k] = a1[k] > 0.f ? g1[k] : 0.f;
       }
     }
+    sg0 += g0; sx0 += g0 * ((y0 - mu) * is);
+    sg1 += g1; sx1 += g1 * ((y1 - mu) * is);
+  }
+  for (; p < p1; p += RL) {
+    const size_t o0 = (size_t)p * C4 + cq;
+    f32x4 g0 = dout[o0];
+    if (out_act) {
+      const f32x4 a0 = out_act[o0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g0[k] = a0[k] > 0.f ? g0[k] : 0.f;
+    }
+    sg0 += g0; sx0 += g0 * ((y[o0] - mu) * is);
+  }
+  sh[0][t] = sg0 + sg1;
+  sh[1][t] = sx0 + sx1;
+  __syncthreads();
+  if (rl == 0) {
+    f32x4 a = sh[0][q], b = sh[1][q];
+    for (int i = 1; i < RL; ++i) {
+      a += sh[0][i * Q + q];
+      b += sh[1][i * Q + q];
+    }
+    reinterpret_cast<f32x4*>(red)[(size_t)blockIdx.y * C4 + cq] = a;
+    reinterpret_cast<f32x4*>(red)[((size_t)P + blockIdx.y) * C4 + cq] = b;
   }
 }
 
 extern "C" int dt_bn_bwd_reduce(const float* dout, const float* out_act, const float* y, const float* mean,
                                 const float* invstd, float* red, int64_t n_pix, int C, void* stream) {
-  DT_REQUIRE(dout && y && mean && invstd && red && n_pix > 0 && C > 0 && (C & 3) == 0 && C <= 1024,
-             "bn_bwd_reduce: bad args");
-  const int P = dt_bn_bwd_rows(n_pix, C);
+  DT_REQUIRE(dout && y && mean && invstd && red && n_pix > 0 && C > 0 && (C & 3) == 0, "bn_bwd_reduce: bad args");
   const int C4 = C / 4;
-  const int lanes = C4 < 256 ? C4 : 256;
-  DT_REQUIRE(256 % lanes == 0, "bn_bwd_reduce: C/4 must divide 256 (C=%d)", C);
-  const size_t smem = (size_t)2 * (256 / lanes) * C * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(P), dim3(256), smem, (hipStream_t)stream, dout, out_act, y, mean,
-                     invstd, red, n_pix, C, P);
+  int Q = 64;
+  while (Q > C4) Q >>= 1;
+  DT_REQUIRE(C4 % Q == 0, "bn_bwd_reduce: C/4 must be a power of two or a multiple of 64 (C=%d)", C);
+  const int P = dt_bn_bwd_rows(n_pix, C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C4 / Q, P), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dout,
+                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, red, n_pix, C4, Q, P);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -267,13 +331,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 }
 
 extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
-                               const float* invstd, const float* gamma, const float* red, int P, float* dgamma,
+                               const float* invstd, const float* gamma, float* red, int P, float* dgamma,
                                float* dbeta, float* dy, float* dres, int dres_accumulate, int64_t n_pix, int C,
                                void* stream) {
   DT_REQUIRE(dout && y && mean && invstd && gamma && red && dgamma && dbeta && dy && n_pix > 0 && C > 0 &&
                  (C & 3) == 0 && P > 0,
              "bn_bwd_apply: bad args");
   hipStream_t st = (hipStream_t)stream;
+  if (P > BN_STAGE1_MIN_ROWS) {
+    const int PB = dt_reduce_rows_out(P, BN_STAGE1_RB);
+    float* scratch = red + (size_t)2 * P * C;
+    int rc = dt_reduce_rows_launch(red, scratch, 2, P, C, BN_STAGE1_RB, st);
+    if (rc != DT_OK) return rc;
+    red = scratch;
+    P = PB;
+  }
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dt_cdiv(C, 16)), dim3(256), 0, st, red, P, C, dgamma, dbeta);
   DT_LAUNCH_CHECK();
   const int64_t n4 = n_pix * C / 4;

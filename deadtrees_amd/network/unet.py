@@ -110,7 +110,7 @@ class UNetEngine:
             P = self.lib.dt_conv2d_stat_rows(C.byref(desc))
             if P <= 0:
                 raise RuntimeError(f"dt_conv2d_stat_rows: {self.lib.dt_last_error().decode()}")
-            stats = self._buf("bn_stats", 2 * P * c.cout, device=dev)
+            stats = self._buf("bn_stats", self.lib.dt_bn_stats_floats(P, c.cout), device=dev)
             self._conv(desc, src0, src1, w, y, None, stats)
             _lib.check(self.lib.dt_bn_finalize(_p(stats), P, c.cout, float(B * Ho * Wo), _p(gamma), _p(beta),
                                                BN_EPS, BN_MOMENTUM, _p(rmean), _p(rvar), _p(mean), _p(invstd),
@@ -226,7 +226,7 @@ class UNetEngine:
         invstd = bnws[nb + c.bn_off: nb + c.bn_off + Cc]
         gamma = params[c.g_off:c.g_off + Cc]
         P = self.lib.dt_bn_bwd_rows(n_pix, Cc)
-        red = self._buf("bn_red", 2 * P * Cc, device=y.device)
+        red = self._buf("bn_red", self.lib.dt_bn_bwd_red_floats(n_pix, Cc), device=y.device)
         st = _stream()
         _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(red), n_pix, Cc,
                                              st), "dt_bn_bwd_reduce")

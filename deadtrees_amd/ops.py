@@ -58,9 +58,11 @@ def conv2d(src0, w_hwio, k, stride, pad, src1=None, mode0=0, split=0, out0=None,
         P = lib.dt_conv2d_stat_rows(C.byref(d))
         if P <= 0:
             raise RuntimeError(lib.dt_last_error().decode())
-        stats = torch.empty((2, P, Cout), dtype=torch.float32, device=dev)
+        stats = torch.empty(lib.dt_bn_stats_floats(P, Cout), dtype=torch.float32, device=dev)
     _lib.check(lib.dt_conv2d(C.byref(d), _p(src0), _p(src1), _p(w_hwio.contiguous()), _p(out0), _p(out1), _p(stats),
                              _st()), "dt_conv2d")
+    if stats is not None:
+        stats = stats[:2 * P * Cout].view(2, P, Cout)
     return out0, out1, stats
 
 
@@ -97,6 +99,9 @@ def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None, 
     _gpu(stats, gamma, beta)
     _, P, Cc = stats.shape
     dev = stats.device
+    full = torch.empty(_lib.load().dt_bn_stats_floats(P, Cc), dtype=torch.float32, device=dev)
+    full[:2 * P * Cc] = stats.reshape(-1)
+    stats = full
     mean, invstd, scale, shift = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(4))
     _lib.check(_lib.load().dt_bn_finalize(_p(stats), P, Cc, float(count), _p(gamma), _p(beta), eps, momentum,
                                           _p(running_mean), _p(running_var), _p(mean), _p(invstd), _p(scale),
@@ -119,7 +124,7 @@ def bn_backward(dout, out_act, y, mean, invstd, gamma, want_dres=False):
     Cc = y.shape[-1]
     n_pix = y.numel() // Cc
     P = lib.dt_bn_bwd_rows(n_pix, Cc)
-    red = torch.empty((2, P, Cc), dtype=torch.float32, device=y.device)
+    red = torch.empty(lib.dt_bn_bwd_red_floats(n_pix, Cc), dtype=torch.float32, device=y.device)
     _lib.check(lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(red), n_pix, Cc, _st()),
                "dt_bn_bwd_reduce")
     dgamma = torch.empty(Cc, dtype=torch.float32, device=y.device)

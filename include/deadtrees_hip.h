@@ -85,7 +85,10 @@ int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const float* src1,
 /* stats[2][P][C] -> batch mean / biased var over `count` elements; writes mean, invstd, and the fused
  * affine scale = gamma*invstd, shift = beta - mean*scale; updates running stats with `momentum`
  * (unbiased var), as torch BatchNorm2d(train).  fp64 accumulation, fixed order. */
-int dt_bn_finalize(const float* stats, int P, int C, double count, const float* gamma, const float* beta,
+/* The stats buffer (also the one dt_conv2d writes) must hold dt_bn_stats_floats(P,C) floats: the
+ * [2][P][C] partial rows plus a scratch tail used by the first reduction stage when P is large. */
+int64_t dt_bn_stats_floats(int P, int C);
+int dt_bn_finalize(float* stats, int P, int C, double count, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* eval mode: scale/shift from running stats. */
@@ -97,14 +100,15 @@ int dt_bn_act(const float* y, const float* scale, const float* shift, const floa
               const float* rscale, const float* rshift, float* out, int64_t n_pix, int C, int relu,
               void* stream);
 /* BN backward, pass 1: g = dout * (out>0 if out_act else 1); partial sums of g and g*xhat per channel
- * -> red[2][P][C] with P = dt_bn_bwd_rows(n_pix). */
+ * -> red[2][P][C] with P = dt_bn_bwd_rows(n_pix); `red` holds dt_bn_bwd_red_floats(n_pix,C) floats. */
 int dt_bn_bwd_rows(int64_t n_pix, int C);
+int64_t dt_bn_bwd_red_floats(int64_t n_pix, int C);  /* size of `red` in floats (rows + reduction scratch) */
 int dt_bn_bwd_reduce(const float* dout, const float* out_act, const float* y, const float* mean,
                      const float* invstd, float* red, int64_t n_pix, int C, void* stream);
 /* pass 2: reduces red -> dgamma, dbeta (fp64, fixed order) and writes
  * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));  if dres != NULL also dres (+)= g. */
 int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
-                    const float* invstd, const float* gamma, const float* red, int P,
+                    const float* invstd, const float* gamma, float* red, int P,
                     float* dgamma, float* dbeta, float* dy, float* dres, int dres_accumulate,
                     int64_t n_pix, int C, void* stream);
 
