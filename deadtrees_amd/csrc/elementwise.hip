@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const f32x4* __restrict__ y
     }
     if (relu) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];   // NaN stays NaN, like torch.relu
     }
     out[i] = v;
   }

@@ -1,0 +1,95 @@
+"""``DeadtreesDataModule`` surface (reference deadtrees/data/deadtreedata.py:192-405) with a synthetic source.
+
+The reference streams webdataset shards through albumentations on CPU workers; neither package nor any shard
+is available here, and at >400 tiles/s/GPU the real loader is the limiter anyway (§8 f2).  This
+module keeps the constructor / ``setup`` / ``*_dataloader`` surface and the batch formats
+(``{"main": (img, mask, distmap, lu, stats)}`` for train/val :348-395, a bare tuple for test :397-405) and
+fills them with synthetic tiles of the reference's shape; ``val_transform`` is the reference normalisation
+(:148-154) in numpy.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .synthetic import MEAN, STD, synth_batch
+
+
+class DeadtreeDatasetConfig:
+    """reference deadtreedata.py:27-34"""
+    mean = np.array(MEAN)
+    std = np.array(STD)
+    tile_size = 256
+    fractions = [0.7, 0.2, 0.1]
+
+
+def val_transform(image: np.ndarray, mask: Optional[np.ndarray] = None):
+    """albumentations ``Normalize(mean, std)`` + ``ToTensorV2`` of deadtreedata.py:148-154: HWC uint8 -> CHW f32"""
+    c = image.shape[-1]
+    mean = (np.asarray(MEAN[:c], dtype=np.float32) * 255.0)
+    inv = 1.0 / (np.asarray(STD[:c], dtype=np.float32) * 255.0)
+    img = (image.astype(np.float32) - mean) * inv
+    out = {"image": torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1)))}
+    if mask is not None:
+        out["mask"] = torch.from_numpy(mask)
+    return out
+
+
+class _SyntheticLoader:
+    def __init__(self, n_batches, batch_size, size, in_channels, classes, seed, wrap_main, device, with_distmap):
+        self.n, self.bs, self.size, self.c, self.k = n_batches, batch_size, size, in_channels, classes
+        self.seed, self.wrap, self.device, self.with_distmap = seed, wrap_main, device, with_distmap
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            img, mask = synth_batch(self.bs, self.size, self.size, self.c, self.k, seed=self.seed + i)
+            dist = torch.zeros((self.bs, self.k, self.size, self.size), dtype=torch.float32)
+            lu = torch.ones_like(mask)
+            stats = [{"file": f"synthetic_{self.seed + i}_{j}", "frac": float((mask[j] > 0).float().mean())}
+                     for j in range(self.bs)]
+            if self.device:
+                img, mask, dist, lu = (t.to(self.device) for t in (img, mask, dist, lu))
+            item = (img, mask, dist, lu, stats)
+            yield {"main": item} if self.wrap else item
+
+
+class DeadtreesDataModule:
+    def __init__(self, data_dir=None, pattern=None, pattern_extra=None, batch_size_extra=None,
+                 train_dataloader_conf=None, val_dataloader_conf=None, test_dataloader_conf=None,
+                 synthetic_batches: int = 8, tile_size: int = 256, device: Optional[str] = None):
+        self.data_dir, self.pattern = data_dir, pattern
+        self.train_conf = dict(train_dataloader_conf or {})
+        self.val_conf = dict(val_dataloader_conf or {})
+        self.test_conf = dict(test_dataloader_conf or {})
+        self.synthetic_batches, self.tile_size, self.device = synthetic_batches, tile_size, device
+        self.in_channels, self.classes = 3, 2
+
+    def setup(self, stage=None, split_fractions=None, in_channels: int = 3, classes: int = 2):
+        if data_dir_has_shards(self.data_dir):
+            raise NotImplementedError("webdataset shards need the `webdataset`/`albumentations` packages "
+                                      "(absent here); only the synthetic source is built")
+        self.in_channels, self.classes = in_channels, classes
+
+    def _loader(self, conf, seed, wrap):
+        return _SyntheticLoader(self.synthetic_batches, int(conf.get("batch_size", 8)), self.tile_size,
+                                self.in_channels, self.classes, seed, wrap, self.device, True)
+
+    def train_dataloader(self):
+        return self._loader(self.train_conf, 1000, True)
+
+    def val_dataloader(self):
+        return self._loader(self.val_conf, 2000, True)
+
+    def test_dataloader(self):
+        return self._loader(self.test_conf, 3000, False)
+
+
+def data_dir_has_shards(data_dir) -> bool:
+    import glob
+    import os
+    return bool(data_dir) and bool(glob.glob(os.path.join(str(data_dir), "*.tar")))

@@ -1,0 +1,232 @@
+"""``SemSegment`` — host-side mirror of the reference LightningModule (deadtrees/network/segmodel.py:57-438)
+over the MI355X-native network and fused losses.
+
+Kept from the reference: constructor ``SemSegment(network, training)`` (:58), attributes ``model``,
+``encoder_weights``, ``classes``, ``classes_int``, ``in_channels``, ``hparams`` (:85-100), the loss-list
+parsing and its errors (:109-143), ``alpha`` (:157-160), ``training_step`` / ``validation_step`` /
+``test_step`` return contracts (:210-289), the ``{stage}/...`` log keys (:185-208), ``configure_optimizers``
+(:420-429) and the non-finite-loss rule (``training_step`` returns ``None`` :220-222).
+
+Different on purpose (MI355X-first): ``self.model`` is ``UNetHIP`` (hand-written HIP kernels) instead of
+``smp.Unet``; one-hot, softmax, every loss term and both F-scores come from ONE fused reduction pass
+(deadtrees_amd/loss/seg_loss.py) instead of ~25 ATen launches and two ``torch.unique(.cpu())`` host syncs per
+step (reference loss/losses.py:37-42,129,139).  The base class is ``pytorch_lightning.LightningModule`` when that
+package is importable and a minimal stand-in otherwise (it is absent from this image).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+from collections import Counter
+from pathlib import Path
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ..loss.seg_loss import seg_loss
+from ..utils.config import AttrDict, to_attrdict
+from .unet import UNetHIP
+
+log = logging.getLogger(__name__)
+
+try:  # pragma: no cover - not installed in the build image
+    import pytorch_lightning as pl  # type: ignore
+    _Base = pl.LightningModule
+    HAVE_LIGHTNING = True
+except Exception:  # noqa: BLE001
+    HAVE_LIGHTNING = False
+
+    class _Base(torch.nn.Module):  # minimal LightningModule-shaped base
+        def __init__(self):
+            super().__init__()
+            self.hparams = AttrDict()
+            self.current_epoch = 0
+            self.trainer = None
+            self.logger = []
+            self.logged: Dict[str, list] = {}
+
+        def save_hyperparameters(self, **kw):
+            self.hparams.update(kw)
+
+        def log(self, name, value, on_step=False, on_epoch=True, **_):
+            self.logged.setdefault(name, []).append(value.detach() if isinstance(value, Tensor) else value)
+
+        def epoch_means(self) -> Dict[str, float]:
+            """mean of per-batch values, what Lightning logs with on_epoch=True"""
+            out = {k: float(torch.stack([torch.as_tensor(x, dtype=torch.float64).cpu() for x in v]).mean())
+                   for k, v in self.logged.items() if v}
+            self.logged.clear()
+            return out
+
+
+def concat_extra(img, mask, distmap, lu, stats, *, extra):
+    """reference segmodel.py:31-40"""
+    e_img, e_mask, e_dist, e_lu, e_stats = list(zip(*extra))
+    img = torch.cat((img, *e_img), dim=0)
+    mask = torch.cat((mask, *e_mask), dim=0)
+    distmap = torch.cat((distmap, *e_dist), dim=0)
+    lu = torch.cat((lu, *e_lu), dim=0)
+    stats = list(stats) + sum((list(s) for s in e_stats), [])
+    return img, mask, distmap, lu, stats
+
+
+def create_combined_batch(batch: Dict[str, Any]):
+    """reference segmodel.py:43-54: ``{"main": (...), "extra_i": (...)}`` -> concatenated tensors"""
+    img, mask, distmap, lu, stats = batch["main"]
+    extra = [v for k, v in batch.items() if k.startswith("extra")]
+    if extra:
+        img, mask, distmap, lu, stats = concat_extra(img, mask, distmap, lu, stats, extra=extra)
+    return img, mask, distmap, lu, stats
+
+
+_SUPPORTED_ELSEWHERE = ("unetplusplus", "unet++", "resunet", "resunetplusplus", "resunet++",
+                        "efficientunetplusplus", "efficientunet++")
+
+
+class SemSegment(_Base):
+    def __init__(self, network, training):
+        super().__init__()
+        network = to_attrdict(network)
+        training = to_attrdict(training)
+        architecture = network.architecture.lower().strip()
+        if architecture == "unet":
+            Model = UNetHIP
+        elif architecture in _SUPPORTED_ELSEWHERE:
+            raise NotImplementedError(
+                f"architecture {architecture!r} exists in the reference but has no MI355X kernels in this build "
+                "(hot path = unet/resnet34, SURVEY.md §8)")
+        else:
+            raise NotImplementedError(
+                "Currently only Unet, ResUnet, Unet++, ResUnet++, and EfficientUnet++ architectures are supported")
+
+        clean = network.copy()
+        del clean.architecture
+        del clean.losses
+        n_classes = len(clean.classes)
+        del clean.classes
+
+        self.model = Model(**clean, classes=n_classes)
+        if clean.get("encoder_weights") is None:
+            log.info("Initializing unset weights with Kaiming")
+            self.model.reset_parameters()
+        self.encoder_weights = clean.get("encoder_weights")
+
+        if HAVE_LIGHTNING:
+            self.save_hyperparameters()
+        else:
+            self.save_hyperparameters(network=network, training=training)
+
+        self.classes = self.hparams["network"]["classes"]
+        self.classes_int = list(range(len(self.classes)))
+        self.classes_int_wout_bg = [c for c in self.classes_int if c != 0]
+        self.in_channels = self.hparams["network"]["in_channels"]
+
+        self.initial_alpha = 0.01
+        self.boundary_loss_ramped = False
+        losses = list(network.losses)
+        assert (("GDICE" in losses) and ("DICE" in losses)) is False, f"Only GDICE _OR_ DICE allowed {losses}"
+        self.loss_names = []
+        for comp in losses:
+            if comp in ("GDICE", "DICE", "FOCAL", "BOUNDARY"):
+                self.loss_names.append(comp)
+            elif comp == "BOUNDARY-RAMPED":
+                self.loss_names.append(comp)
+                self.boundary_loss_ramped = True
+            elif comp == "GWDICE":
+                raise NotImplementedError("GWDICE is not on the MI355X hot path yet (SURVEY.md §8 f4)")
+            else:
+                raise NotImplementedError(f"The loss component <{comp}> is not recognized")
+        log.info(f"Losses: {losses}")
+        assert any(n in ("GDICE", "DICE") for n in self.loss_names)  # "we require GDICE!" (segmodel.py:143)
+
+        self.stats = {"train": Counter(), "val": Counter(), "test": Counter()}
+        self.label_error = None  # device flag: labels outside [0,K) seen (class2one_hot's assert, lazily)
+
+    # ------------------------------------------------------------------ reference helpers
+    @property
+    def alpha(self):
+        """blending parameter for boundary loss - ramps 0.01 -> 0.99 by epoch (segmodel.py:157-160)"""
+        return min((self.current_epoch + 1) * self.initial_alpha, 0.99)
+
+    def calculate_loss(self, logits: Tensor, mask: Tensor, stage: str, distmap: Optional[Tensor] = None):
+        """compound loss of segmodel.py:169-200, from LOGITS and integer LABELS (fused softmax / one-hot).
+        Returns (loss, parts) and logs the reference's keys."""
+        use_dist = distmap if any(n.startswith("BOUNDARY") for n in self.loss_names) else None
+        loss, parts, err = seg_loss(logits, mask, use_dist, self.loss_names, alpha=self.alpha)
+        self.label_error = err
+        self.log(f"{stage}/dice_loss", parts["dice_loss"], on_step=False, on_epoch=True)
+        if use_dist is not None:
+            self.log(f"{stage}/boundary_loss", parts["boundary_loss"], on_step=False, on_epoch=True)
+        if "FOCAL" in self.loss_names:
+            self.log(f"{stage}/focal_loss", parts["focal_loss"], on_step=False, on_epoch=True)
+        self.log(f"{stage}/total_loss", loss, on_step=False, on_epoch=True)
+        return loss, parts
+
+    def log_metrics(self, parts, *, stage: str):
+        self.log(f"{stage}/dice", parts["dice"], on_step=False, on_epoch=True)
+        self.log(f"{stage}/dice_with_bg", parts["dice_with_bg"], on_step=False, on_epoch=True)
+
+    # ------------------------------------------------------------------ steps
+    def training_step(self, batch, batch_idx):
+        img, mask, distmap, _, stats = create_combined_batch(batch)
+        logits = self.model(img)
+        loss, parts = self.calculate_loss(logits, mask, "train", distmap=distmap)
+        if torch.isnan(loss) or torch.isinf(loss):   # the one host sync per step the reference also has
+            log.warning("Train loss is NaN! What is going on?")
+            return None
+        self.log_metrics(parts, stage="train")
+        self.stats["train"].update([x["file"] for x in stats])
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        img, mask, distmap, lu, stats = create_combined_batch(batch)
+        logits = self.model(img)
+        loss, parts = self.calculate_loss(logits, mask, stage="val", distmap=distmap)
+        self.log_metrics(parts, stage="val")
+        self.stats["val"].update([x["file"] for x in stats])
+        return {"val_loss": loss, "target": mask, "prediction": logits.argmax(dim=1), "lu": lu}
+
+    def test_step(self, batch: Tuple[Tensor], batch_idx) -> Dict[str, Any]:
+        img, mask, _, lu, stats = batch
+        logits = self.model(img)
+        _, parts, err = seg_loss(logits, mask, None, [n for n in self.loss_names if not n.startswith("BOUNDARY")])
+        self.label_error = err
+        self.log_metrics(parts, stage="test")
+        self.stats["test"].update([x["file"] for x in stats])
+        return {"target": mask, "prediction": logits.argmax(dim=1), "lu": lu}
+
+    def configure_optimizers(self):
+        opt = torch.optim.Adam(self.parameters(), lr=self.hparams["training"]["learning_rate"])
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=self.hparams["training"]["cosineannealing_tmax"])
+        return [opt], [sch]
+
+    # ------------------------------------------------------------------ checkpoints (plain, pickle-free payload)
+    def save_checkpoint(self, path):
+        """writes a ``.ckpt`` that ``load_from_checkpoint`` reads with ``weights_only=True``: tensors under the
+        reference's ``state_dict`` keys (``model.`` prefix) + hyper-parameters as a JSON string."""
+        sd = {f"model.{k}": v for k, v in self.model.smp_state_dict().items()}
+        hp = {"network": dict(self.hparams["network"]), "training": dict(self.hparams["training"])}
+        torch.save({"state_dict": sd, "hyper_parameters_json": json.dumps(hp)}, str(path))
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu", **_):
+        if HAVE_LIGHTNING:  # pragma: no cover
+            try:
+                return super().load_from_checkpoint(path, map_location=map_location)
+            except Exception:  # noqa: BLE001 - fall through to the plain format
+                pass
+        ck = torch.load(str(path), map_location=map_location, weights_only=True)
+        if "hyper_parameters_json" not in ck:
+            raise RuntimeError("Lightning checkpoints with pickled omegaconf hyper-parameters cannot be read without "
+                               "pytorch_lightning/omegaconf; re-save with SemSegment.save_checkpoint")
+        hp = json.loads(ck["hyper_parameters_json"])
+        m = cls(hp["network"], hp["training"])
+        m.model.load_smp_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items()})
+        return m
+
+
+def cosine_lr(base_lr: float, epoch: int, t_max: int, eta_min: float = 0.0) -> float:
+    """closed form of torch CosineAnnealingLR stepped once per epoch (segmodel.py:426-428)"""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2

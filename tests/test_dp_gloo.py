@@ -1,0 +1,68 @@
+"""world_size-2 CPU (gloo) tests of the data-parallel pieces: bucketed gradient all-reduce over ranges of
+the flat buffer, and tile-queue sharding of the tiled inference driver."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deadtrees_amd.network.spec import build_spec
+        from deadtrees_amd.trainer import GradReducer
+        spec = build_spec(3, 2)
+        n = spec.n_params
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = torch.randn(n, generator=g)
+        mine = grads.clone()
+        red = GradReducer()
+        red.attach(grads)
+        for name, lo, hi in spec.buckets:        # the order backward produces them
+            red.hook(name, lo, hi)
+        red.wait()
+        other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+        ok = torch.allclose(grads, mine + other, rtol=0, atol=0)
+
+        # tile-queue sharding: fake inference = threshold of channel 0
+        from deadtrees_amd.deployment.tiler import infer_tile
+
+        class Fake:
+            def run_u8(self, u8, device="cpu"):
+                return (u8[..., 0] > 127).to(torch.uint8)
+        rng = np.random.default_rng(0)
+        arr = rng.integers(0, 256, (4, 512, 512), dtype=np.uint8)
+        out = infer_tile(Fake(), arr, subtile=128, batch_size=4, rank=rank, world=world, device="cpu")
+        ok2 = np.array_equal(out, (arr[0] > 127).astype(np.uint8))
+        q.put((rank, bool(ok), bool(ok2)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_allreduce_and_tile_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), "bucketed all-reduce mismatch"
+    assert all(r[2] for r in res), "sharded tiled inference mismatch"

@@ -1,0 +1,165 @@
+"""Host-side logic of the product path that needs no GPU: layer spec, state_dict conversion, SemSegment
+surface and its error behaviour, block split/merge, transforms, and the loud failure without a device."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spec_counts_and_buckets():
+    from deadtrees_amd.network.spec import build_spec, smp_param_shapes
+    s = build_spec(3, 2)
+    assert s.n_true_params == 24_436_514
+    assert build_spec(3, 1).n_true_params == 24_436_369
+    assert build_spec(4, 3).n_true_params == 24_436_514 + 7 * 7 * 64 + 9 * 16 + 1
+    assert len(s.convs) == 47 and sum(c.bn_key is not None for c in s.convs) == 46
+    # buckets tile the flat buffer in reverse (gradient-ready) order without gaps
+    spans = [(lo, hi) for _, lo, hi in s.buckets]
+    assert spans[0][1] == s.n_params and spans[-1][0] == 0
+    for (lo, hi), (lo2, hi2) in zip(spans, spans[1:]):
+        assert lo == hi2
+    assert [round((hi - lo) * 4 / 1e6, 1) for lo, hi in spans] == [12.6, 52.5, 27.3, 4.5, 0.9]
+    shapes = smp_param_shapes(s)
+    assert shapes["decoder.blocks.0.conv1.0.weight"] == (256, 768, 3, 3)
+    assert shapes["segmentation_head.0.bias"] == (2,)
+
+
+def test_state_dict_matches_oracle_keys_and_roundtrips():
+    from deadtrees_amd.network.unet import UNetHIP
+    from oracle.unet_ref import make_oracle
+    ref = make_oracle(4, 3, seed=3)
+    m = UNetHIP(in_channels=4, classes=3)
+    missing, unexpected = m.load_state_dict(ref.state_dict())
+    assert not missing and not unexpected
+    sd = m.state_dict()
+    assert list(sd.keys()) != [] and set(sd.keys()) == set(ref.state_dict().keys())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(sd[k], v), k
+    with pytest.raises(RuntimeError):
+        m.load_smp_state_dict({k: v for k, v in ref.state_dict().items() if "layer3" not in k})
+    bad = dict(ref.state_dict())
+    bad["encoder.conv1.weight"] = torch.zeros(64, 3, 7, 7)
+    with pytest.raises(RuntimeError):
+        m.load_smp_state_dict(bad)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.loss.seg_loss import seg_loss
+    m = UNetHIP()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        seg_loss(torch.zeros(1, 2, 8, 8), torch.zeros(1, 8, 8, dtype=torch.int64))
+    src = open(os.path.join(ROOT, "deadtrees_amd", "network", "unet.py")).read()
+    for mod in ("unet.py", "segmodel.py"):
+        assert "import oracle" not in open(os.path.join(ROOT, "deadtrees_amd", "network", mod)).read()
+    assert "oracle" not in src.replace("oracle/", "")
+
+
+def test_no_product_module_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "deadtrees_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "from oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_semsegment_surface_and_errors():
+    from deadtrees_amd.network.segmodel import SemSegment, create_combined_batch, cosine_lr
+    from deadtrees_amd.utils.config import default_network, default_training
+    m = SemSegment(default_network(), default_training())
+    assert m.classes == ["background", "deadtree"] and m.classes_int == [0, 1] and m.in_channels == 3
+    assert m.encoder_weights is None and m.loss_names == ["GDICE", "FOCAL"]
+    assert m.alpha == 0.01
+    m.current_epoch = 200
+    assert m.alpha == 0.99
+    (opt,), (sch,) = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 3e-4 and sch.T_max == 10
+    assert any(k.startswith("model.encoder.conv1") for k in m.state_dict())
+    with pytest.raises(NotImplementedError):
+        SemSegment(default_network(architecture="fancynet"), default_training())
+    with pytest.raises(NotImplementedError):
+        SemSegment(default_network(architecture="efficientunet++"), default_training())
+    with pytest.raises(AssertionError):
+        SemSegment(default_network(losses=["GDICE", "DICE"]), default_training())
+    with pytest.raises(NotImplementedError):
+        SemSegment(default_network(losses=["GDICE", "HINGE"]), default_training())
+    with pytest.raises(AssertionError):
+        SemSegment(default_network(losses=["FOCAL"]), default_training())
+    # batch plumbing (segmodel.py:31-54)
+    a = (torch.zeros(2, 3, 4, 4), torch.zeros(2, 4, 4, dtype=torch.int64), torch.zeros(2, 2, 4, 4),
+         torch.zeros(2, 4, 4, dtype=torch.int64), [{"file": "a"}, {"file": "b"}])
+    b = (torch.ones(1, 3, 4, 4), torch.ones(1, 4, 4, dtype=torch.int64), torch.ones(1, 2, 4, 4),
+         torch.ones(1, 4, 4, dtype=torch.int64), [{"file": "c"}])
+    img, mask, dist, lu, stats = create_combined_batch({"main": a, "extra_0": b})
+    assert img.shape[0] == 3 and [s["file"] for s in stats] == ["a", "b", "c"]
+    # scheduler closed form == torch
+    p = torch.nn.Parameter(torch.zeros(1))
+    o = torch.optim.Adam([p], lr=3e-4)
+    s = torch.optim.lr_scheduler.CosineAnnealingLR(o, T_max=10)
+    for ep in range(1, 8):
+        o.step()
+        s.step()
+        assert cosine_lr(3e-4, ep, 10) == pytest.approx(o.param_groups[0]["lr"], rel=1e-9)
+
+
+def test_checkpoint_roundtrip_and_inference_errors(tmp_path):
+    from deadtrees_amd.deployment.inference import PyTorchInference
+    from deadtrees_amd.network.segmodel import SemSegment
+    from deadtrees_amd.utils.config import default_network, default_training
+    m = SemSegment(default_network(in_channels=4, classes=["a", "b", "c"]), default_training())
+    p = tmp_path / "m.ckpt"
+    m.save_checkpoint(p)
+    m2 = SemSegment.load_from_checkpoint(p)
+    assert m2.in_channels == 4 and len(m2.classes) == 3
+    assert torch.equal(m2.model.flat_params, m.model.flat_params)
+    with pytest.raises(ValueError):
+        PyTorchInference(tmp_path / "m.onnx")
+    inf = PyTorchInference(p)
+    with pytest.raises(TypeError):
+        inf.run(np.zeros((3, 8, 8)))
+
+
+def test_blocks_match_reference_known_answer(golden_dir):
+    from deadtrees_amd.deployment.tiler import Tiler, make_blocks_vectorized, unmake_blocks_vectorized
+    z = np.load(os.path.join(golden_dir, "blocks.npz"))
+    np.testing.assert_array_equal(make_blocks_vectorized(z["toy"], 2), z["toy_blocks"])        # tests/test_tiler.py:56-77
+    np.testing.assert_array_equal(unmake_blocks_vectorized(z["toy_blocks"][:, 0], 2, 4, 4), z["toy"][0])
+    rng = np.random.default_rng(int(z["big_seed"]))
+    big = rng.integers(0, 256, (4, 512, 512), dtype=np.uint8)
+    blocks = make_blocks_vectorized(big, 256)
+    assert hashlib.sha256(blocks.tobytes()).hexdigest() == str(z["big_blocks_sha256"])
+    assert hashlib.sha256(unmake_blocks_vectorized(blocks[:, 1], 256, 512, 512).tobytes()).hexdigest() == str(
+        z["big_merged_sha256"])
+    t = Tiler(512, 256)
+    t.load_array(big[:, :500, :300])
+    batches = t.get_batches(2)
+    assert sum(len(b) for b in batches) == 4 and batches[0].shape[1:] == (4, 256, 256)
+    back = t.put_batches([b[:, 2] for b in batches])
+    np.testing.assert_array_equal(back, big[2, :500, :300])
+    with pytest.raises(ValueError):
+        Tiler(2048, 300)
+
+
+def test_transforms_and_synthetic_data():
+    from deadtrees_amd.data.deadtreedata import DeadtreesDataModule, val_transform
+    from deadtrees_amd.data.synthetic import MEAN, STD, synth_batch
+    img = np.random.default_rng(0).integers(0, 256, (16, 16, 4), dtype=np.uint8)
+    out = val_transform(image=img)["image"]
+    assert out.shape == (4, 16, 16) and out.dtype == torch.float32
+    want = (img.astype(np.float64) / 255.0 - np.array(MEAN)) / np.array(STD)
+    np.testing.assert_allclose(out.numpy(), want.transpose(2, 0, 1), rtol=1e-5, atol=1e-5)
+    a, la = synth_batch(2, 64, 64, 3, 2, seed=5)
+    b, lb = synth_batch(2, 64, 64, 3, 2, seed=5)
+    assert torch.equal(a, b) and torch.equal(la, lb) and int(la[0].sum()) == 0 and la.dtype == torch.int64
+    dm = DeadtreesDataModule(train_dataloader_conf={"batch_size": 2}, synthetic_batches=2, tile_size=64)
+    dm.setup(in_channels=3, classes=2)
+    batch = next(iter(dm.train_dataloader()))
+    img_t, mask, dist, lu, stats = batch["main"]
+    assert img_t.shape == (2, 3, 64, 64) and dist.shape == (2, 2, 64, 64) and len(stats) == 2
+    assert isinstance(next(iter(dm.test_dataloader())), tuple)

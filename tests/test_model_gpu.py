@@ -137,7 +137,7 @@ def test_fused_losses_vs_reference_golden(path):
         total, parts, err = seg_loss(lg, mask, dist if "BOUNDARY" in names else None, names)
         total.backward()
         assert int(err) == 0
-        assert float(total) == pytest.approx(float(z[f"loss[{combo}]"]), rel=1e-5, abs=1e-6)
+        assert float(total.detach()) == pytest.approx(float(z[f"loss[{combo}]"]), rel=1e-5, abs=1e-6)
         ref = z[f"dlogits[{combo}]"]
         np.testing.assert_allclose(lg.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max() + 1e-10)
         if "GDICE" in names:
