@@ -51,12 +51,19 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback on the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    # DT_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box
+    backend = os.environ.get("DT_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from deadtrees_amd.data.synthetic import synth_batch
     from deadtrees_amd.network.unet import UNetHIP

@@ -52,6 +52,7 @@ SIGNATURES = {
     "dt_normalize_u8": (C.c_int, [c_f, c_f, I64, C.c_int, C.c_int, C.POINTER(F32), C.POINTER(F32), c_f]),
     "dt_head_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_head_bwd_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dt_head_bwd_red_floats": (I64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dt_head_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_head_bwd_finalize": (C.c_int, [c_f, C.c_int, c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_acc_doubles": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),

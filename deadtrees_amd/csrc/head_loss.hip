@@ -114,7 +114,6 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __shared__ float xt[HH * HW_][C + 1];
   __shared__ float dlt[K][HH * HW_];
   __shared__ float wl[K * 9 * C];
-  __shared__ float wred[4][NW];
   const int tiles_x = (W + HEAD_TW - 1) / HEAD_TW, tiles_y = (H + HEAD_TH - 1) / HEAD_TH;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
   const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
@@ -169,30 +168,27 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       }
     }
   }
-  // ---- dW / dbias partials: each thread owns its output pixel; wave-reduce each of the NW terms
-  const int lane = t & 63, wave = t >> 6;
-  float g[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) g[k] = valid ? dlt[k][(py + 1) * HW_ + px + 1] : 0.f;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const float* xp = xt[(py + kh) * HW_ + px + kw];
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const float v = wave_sum(g[k] * xp[c]);
-          if (lane == 0) wred[wave][(k * 9 + kh * 3 + kw) * C + c] = v;
-        }
+  // ---- dW / dbias partials: one thread per (k, tap, c) output walks the tile's 256 pixels in LDS
+  // (dl broadcast within a wave, x rows 17-dword pitch): no cross-lane reduction needed.
+  constexpr int NWP = (NW + 3) & ~3;   // row pitch of `red` (multiple of 4 for the vectorised row reduction)
+  for (int o = t; o < NWP; o += 256) {
+    float accw = 0.f;
+    if (o < K * 9 * C) {
+      const int c = o % C, tap = (o / C) % 9, k = o / (9 * C);
+      const int kh = tap / 3, kw = tap % 3;
+      for (int py2 = 0; py2 < HEAD_TH; ++py2) {
+        const float* dlr = &dlt[k][(py2 + 1) * HW_ + 1];
+        const int xrow = (py2 + kh) * HW_ + kw;
+#pragma unroll 8
+        for (int px2 = 0; px2 < HEAD_TW; ++px2) accw = fmaf(dlr[px2], xt[xrow + px2][c], accw);
       }
-    const float vb = wave_sum(g[k]);
-    if (lane == 0) wred[wave][K * 9 * C + k] = vb;
+    } else if (o < NW) {
+      const int k = o - K * 9 * C;
+      for (int py2 = 0; py2 < HEAD_TH; ++py2)
+        for (int px2 = 0; px2 < HEAD_TW; ++px2) accw += dlt[k][(py2 + 1) * HW_ + px2 + 1];
+    }
+    red[(size_t)blockIdx.x * NWP + o] = accw;
   }
-  __syncthreads();
-  for (int i = t; i < NW; i += 256)
-    red[(size_t)blockIdx.x * NW + i] = (wred[0][i] + wred[1][i]) + (wred[2][i] + wred[3][i]);
 }
 
 extern "C" int dt_head_bwd(const float* x, const float* w, const float* dl, float* dx, float* red, int B, int H,
@@ -211,16 +207,16 @@ extern "C" int dt_head_bwd(const float* x, const float* w, const float* dl, floa
   return DT_OK;
 }
 
-__global__ __launch_bounds__(256) void colsum_f64_kernel(const float* __restrict__ red, int P, int N,
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const float* __restrict__ red, int P, int N, int pitch,
                                                          float* __restrict__ out_a, int na,
                                                          float* __restrict__ out_b) {
-  // out[j] = sum_p red[p][j]; one wave per column group of 4, fp64
+  // out[j] = sum_p red[p][j]; 4 columns x 64 row-lanes per workgroup, fp64
   __shared__ double sh[64][5];
   const int j0 = blockIdx.x * 4;
-  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;  // 64 row-lanes
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   double s = 0.0;
   if (j0 + cl < N)
-    for (int p = rl; p < P; p += 64) s += (double)red[(size_t)p * N + j0 + cl];
+    for (int p = rl; p < P; p += 64) s += (double)red[(size_t)p * pitch + j0 + cl];
   sh[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && j0 + cl < N) {
@@ -234,11 +230,27 @@ __global__ __launch_bounds__(256) void colsum_f64_kernel(const float* __restrict
   }
 }
 
-extern "C" int dt_head_bwd_finalize(const float* red, int P, float* dw, float* dbias, int Cin, int K, void* stream) {
+#define HEAD_RED_RB 64
+static inline int head_pitch(int Cin, int K) { return (K * 9 * Cin + K + 3) & ~3; }
+
+extern "C" int64_t dt_head_bwd_red_floats(int B, int H, int W, int Cin, int K) {
+  const int64_t P = dt_head_bwd_rows(B, H, W);
+  return (P + dt_reduce_rows_out((int)P, HEAD_RED_RB)) * head_pitch(Cin, K);
+}
+
+extern "C" int dt_head_bwd_finalize(float* red, int P, float* dw, float* dbias, int Cin, int K, void* stream) {
   DT_REQUIRE(red && dw && dbias && P > 0 && Cin == HEAD_CIN && K >= 1 && K <= HEAD_MAXK, "head_bwd_finalize: bad args");
-  const int na = K * 9 * Cin, N = na + K;
-  hipLaunchKernelGGL(colsum_f64_kernel, dim3(dt_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, red, P, N, dw, na,
-                     dbias);
+  const int na = K * 9 * Cin, N = na + K, pitch = head_pitch(Cin, K);
+  hipStream_t st = (hipStream_t)stream;
+  const float* rows = red;
+  if (P > 256) {
+    float* stage = red + (size_t)P * pitch;
+    int rc = dt_reduce_rows_launch(red, stage, 1, P, pitch, HEAD_RED_RB, st);
+    if (rc != DT_OK) return rc;
+    rows = stage;
+    P = dt_reduce_rows_out(P, HEAD_RED_RB);
+  }
+  hipLaunchKernelGGL(colsum_f64_kernel, dim3(dt_cdiv(N, 4)), dim3(256), 0, st, rows, P, N, pitch, dw, na, dbias);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

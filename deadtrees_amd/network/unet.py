@@ -287,8 +287,7 @@ class UNetEngine:
         K = hd.cout
         g = torch.empty_like(h["x"])
         P = lib.dt_head_bwd_rows(B, H, W)
-        nw = K * 9 * hd.cin + K
-        red = self._buf("head_red", P * nw, device=dev)
+        red = self._buf("head_red", lib.dt_head_bwd_red_floats(B, H, W, hd.cin, K), device=dev)
         wh = params[hd.w_off:hd.w_off + hd.w_size]
         _lib.check(lib.dt_head_bwd(_p(h["x"]), _p(wh), _p(dlogits), _p(g), _p(red), B, H, W, hd.cin, K, st),
                    "dt_head_bwd")

@@ -212,8 +212,7 @@ def head_bwd(x, w_ohwi, dlogits):
     B, H, W, Cin = x.shape
     K = w_ohwi.shape[0]
     P = lib.dt_head_bwd_rows(B, H, W)
-    nw = K * 9 * Cin + K
-    red = torch.empty((P, nw), dtype=torch.float32, device=x.device)
+    red = torch.empty(lib.dt_head_bwd_red_floats(B, H, W, Cin, K), dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     _lib.check(lib.dt_head_bwd(_p(x), _p(w_ohwi.contiguous()), _p(dlogits.contiguous()), _p(dx), _p(red), B, H, W, Cin,
                                K, _st()), "dt_head_bwd")

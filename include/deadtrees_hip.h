@@ -133,10 +133,13 @@ int dt_normalize_u8(const uint8_t* src, float* dst, int64_t n_pix, int Csrc, int
 int dt_head_fwd(const float* x, const float* w_ohwi, const float* bias, float* logits_nchw,
                 int64_t* argmax_i64, uint8_t* argmax_u8, int B, int H, int W, int Cin, int K, void* stream);
 int dt_head_bwd_rows(int B, int H, int W);
-/* dx[B,H,W,Cin], partial dW/dbias rows -> red[P][K*9*Cin + K]; dt_head_bwd_finalize sums them. */
+/* floats the `red` scratch of dt_head_bwd / dt_head_bwd_finalize must hold (partial rows + reduction stage) */
+int64_t dt_head_bwd_red_floats(int B, int H, int W, int Cin, int K);
+/* dx[B,H,W,Cin] and one partial row of dW/dbias per workgroup into red; dt_head_bwd_finalize sums the rows
+ * (two-stage, fixed order) into dw_ohwi[K][3][3][Cin] and dbias[K]. */
 int dt_head_bwd(const float* x, const float* w_ohwi, const float* dlogits_nchw, float* dx, float* red,
                 int B, int H, int W, int Cin, int K, void* stream);
-int dt_head_bwd_finalize(const float* red, int P, float* dw_ohwi, float* dbias, int Cin, int K, void* stream);
+int dt_head_bwd_finalize(float* red, int P, float* dw_ohwi, float* dbias, int Cin, int K, void* stream);
 
 /* ------------------------------------------------------------------ losses & metrics (K12-K18) */
 #define DT_LOSS_NACC 8

@@ -66,3 +66,62 @@ def test_bucketed_allreduce_and_tile_sharding_world2():
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), "bucketed all-reduce mismatch"
     assert all(r[2] for r in res), "sharded tiled inference mismatch"
+
+
+def _gpu_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deadtrees_amd.data.synthetic import synth_batch
+        from deadtrees_amd.network.unet import UNetHIP
+        from deadtrees_amd.trainer import HipTrainer
+        dev = "cuda:0"
+        torch.cuda.set_device(0)
+        img, mask = synth_batch(2, 64, 64, 3, 2, seed=50 + rank)
+        img, mask = img.to(dev), mask.to(dev)
+        # local (un-reduced) gradient of this rank's batch
+        solo = UNetHIP()
+        solo.reset_parameters(seed=3)
+        solo.to(dev)
+        st = HipTrainer(solo)
+        st.step(img, mask)
+        g_local = solo._grad_buffer().clone()
+        p_solo = solo.flat_params.detach().clone()
+        # data-parallel step
+        m = UNetHIP()
+        m.reset_parameters(seed=3 + rank)     # different init per rank: broadcast must fix it
+        m.to(dev)
+        tr = HipTrainer(m, distributed=True)
+        tr.broadcast_parameters(0)
+        tr.step(img, mask)
+        g_sum = m._grad_buffer().clone()
+        gathered = [torch.empty_like(g_local) for _ in range(world)]
+        dist.all_gather(gathered, g_local)
+        ok_sum = torch.equal(g_sum, gathered[0] + gathered[1])     # sum of the independent replicas' gradients
+        ps = [torch.empty_like(m.flat_params.data) for _ in range(world)]
+        dist.all_gather(ps, m.flat_params.data)
+        ok_sync = torch.equal(ps[0], ps[1])                         # replicas stay identical after the update
+        moved = not torch.equal(ps[0], p_solo)                      # and differ from the single-replica update
+        q.put((rank, bool(ok_sum), bool(ok_sync), bool(moved)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_data_parallel_step_equals_sum_of_replica_gradients():
+    """2 ranks sharing one GPU (gloo): after the bucketed all-reduce the flat gradient buffer is bit-equal to the
+    sum of the two replicas' independent gradients (per-replica BatchNorm / GDICE) and the replicas
+    hold identical parameters after the fused clip+Adam step with the 1/N folded into the clip coefficient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] for r in res), "all-reduced gradient != sum of replica gradients"
+    assert all(r[2] for r in res), "replicas diverged"
+    assert all(r[3] for r in res)
