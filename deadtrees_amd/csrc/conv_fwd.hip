@@ -158,8 +158,10 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ lds_in, cons
   }
 }
 
+// narrow-input stride-1 layers (Cin <= 32: one or two chunks, no pipelining depth) run the CK=8 variant at
+// 3 waves/SIMD; everything else 2 waves/SIMD (measured per layer with scripts/bench_conv.py)
 template <int KS, int STRIDE, int TW, int TN, int CK>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) void conv_fwd_kernel(const ConvArgs a) {
   using G = ConvGeom<KS, STRIDE, TW, CK>;
   constexpr int NT = TN / 32;
   constexpr int IN_ELEMS = CK * G::PLANE;
@@ -310,19 +312,32 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvArgs a) {
     const bool nok = n < a.Cout;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+      size_t off[16];
+      bool ok[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * s;
         const int p = (wave * 2 + mt) * 32 + row;
         const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        if (nok && oy < a.Ho && ox < a.Wo) {
-          float v = acc[mt][j][i];
-          s1[j] += v;
-          s2[j] += v * v;
-          const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld + nn;
-          if (a.accumulate && outp == a.out0) v += outp[o];
-          outp[o] = v;
-        }
+        ok[i] = nok && oy < a.Ho && ox < a.Wo;
+        off[i] = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld + nn;
+      }
+      if (a.accumulate && outp == a.out0) {
+        float prev[16];   // all 16 loads in flight before the first add (gradient accumulation joins)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[i] = ok[i] ? outp[off[i]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (ok[i]) outp[off[i]] = acc[mt][j][i] + prev[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (ok[i]) {
+            const float v = acc[mt][j][i];
+            s1[j] += v;
+            s2[j] += v * v;
+            outp[off[i]] = v;
+          }
       }
     }
   }
@@ -432,7 +447,8 @@ extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* 
   a.n_tiles = dt_cdiv(d->Cout, c.tn);
   a.P = d->B * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
-  if (d->ksize == 3 && d->stride == 1) return launch_tw_tn<3, 1, 16>(a, c, st);
+  if (d->ksize == 3 && d->stride == 1)
+    return (d->C0 + d->C1 <= 32) ? launch_tw_tn<3, 1, 8>(a, c, st) : launch_tw_tn<3, 1, 16>(a, c, st);
   if (d->ksize == 3 && d->stride == 2) return launch_tw_tn<3, 2, 8>(a, c, st);
   if (d->ksize == 1 && d->stride == 2) return launch_tw_tn<1, 2, 16>(a, c, st);
   if (d->ksize == 1 && d->stride == 1) return launch_tw_tn<1, 1, 16>(a, c, st);
@@ -482,6 +498,6 @@ extern "C" int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck
   ConvCfg c = pick_cfg(d);
   if (tw) *tw = c.tw;
   if (tn) *tn = d->ksize == 7 ? 64 : c.tn;
-  if (ck) *ck = d->ksize == 7 ? 4 : ((d->ksize == 3 && d->stride == 2) ? 8 : 16);
+  if (ck) *ck = d->ksize == 7 ? 4 : ((d->ksize == 3 && (d->stride == 2 || d->C0 + d->C1 <= 32)) ? 8 : 16);
   return DT_OK;
 }
