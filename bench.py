@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train = BASELINE configs[1] (the headline metric); infer = tiled-inference forward "
+                         "(uint8 tiles -> uint8 class maps, BASELINE configs[4] per-GPU leg)")
     args = ap.parse_args()
 
     import torch
@@ -73,6 +76,8 @@ def main():
     model = UNetHIP(in_channels=3, classes=2)
     model.reset_parameters(seed=0)
     model.to(dev)
+    if args.mode == "infer":
+        return infer_bench(args, model, dev, world, rank, distributed)
     tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed)
     tr.broadcast_parameters(0)
     img, mask = synth_batch(B, S, S, 3, 2, seed=1234 + rank)
@@ -108,25 +113,30 @@ def main():
 
     # ---- roofline of the dominant conv kernel (rank 0's launches)
     agg = {}
-    for name, flops, a, b in prof:
+    for name, flops, a, b, nbytes in prof:
         t = a.elapsed_time(b) * 1e-3
-        r = agg.setdefault(name, [0.0, 0.0, 0])
+        r = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
         r[0] += t
         r[1] += flops
         r[2] += 1
+        r[3] += nbytes
     roof = None
     conv_time = sum(r[0] for r in agg.values())
     if agg:
-        name, (t, fl, n) = max(agg.items(), key=lambda kv: kv[1][0])
+        name, (t, fl, n, nb) = max(agg.items(), key=lambda kv: kv[1][0])
         ach = fl / t / 1e12
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
                 "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
+                "algorithmic_bytes_per_launch": round(nb / n), "algorithmic_flops_per_launch": round(fl / n),
+                "hbm_GBps_algorithmic": round(nb / t / 1e9, 1),
                 "share_of_step": round(t / (float(e0.elapsed_time(e1)) * 1e-3), 4)}
+        # HBM bytes per launch from the PMC passes (profiles/traffic.json: FETCH_SIZE x2 correction for wide
+        # coalesced reads on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs of this command)
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                roof["traffic"] = json.load(open(tfile)).get(name)
+                roof["traffic"] = json.load(open(tfile)).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
     per_gpu_tiles_s = B * args.steps / wall
@@ -160,6 +170,55 @@ def main():
                                          f"B=2, {S}x{S}, {args.cpu_steps} timed steps after 1 warm-up, median)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def infer_bench(args, model, dev, world, rank, distributed):
+    """forward-only leg of the tiled inference path: uint8 RGBN sub-tiles resident in HBM -> normalise (fused
+    kernel) -> U-Net forward (eval BN) -> uint8 class map from the head kernel.  One step = one batch."""
+    import torch
+    import torch.distributed as dist
+    from deadtrees_amd import ops
+    from deadtrees_amd.data.synthetic import MEAN, STD, synth_u8_batch
+    B, S = args.batch, args.size
+    u8 = synth_u8_batch(B, S, S, seed=99 + rank).to(dev)
+    model.eval()
+
+    def step():
+        x = ops.normalize_u8(u8, MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
+        return model.predict_classes(x, dtype="uint8")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    dt = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    wall = float(dt)
+    tiles_s = B * world * args.steps / wall
+    km2_per_tile = (S * 0.20002 / 1000.0) ** 2          # pixel 0.20002 m (scripts/computestats_inference.py:57-59)
+    fwd_flop = 62.59e9 * (S / 512.0) ** 2
+    res = {"metric": f"{S}x{S} RGB tiles/sec (inference fwd + argmax)", "value": round(tiles_s, 1), "unit": "tiles/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"tiled inference leg: uint8 {S}x{S}x4 sub-tiles, batch {B}/GPU, fused normalise + "
+                                  "forward + uint8 argmax", "global_batch": B * world, "parallelism": f"dp{world}"},
+           "km2_per_hour": round(tiles_s * km2_per_tile * 3600.0, 1),
+           "whole_net": {"tflops": round(tiles_s / world * fwd_flop / 1e12, 2),
+                         "mfma_frac": round(tiles_s / world * fwd_flop / 1e12 / PEAK_FP32_TFLOPS, 4)},
+           "foreground_pixels": int(out.sum())}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()
 

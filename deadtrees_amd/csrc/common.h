@@ -47,3 +47,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // rows_per_block RB; N % 4 == 0; fp32 partial sums in a fixed order (deterministic).
 int dt_reduce_rows_launch(const float* in, float* out, int planes, int P, int N, int RB, hipStream_t st);
 static inline int dt_reduce_rows_out(int P, int RB) { return (P + RB - 1) / RB; }
+
+// XCD-aware workgroup id remap (bijective for any grid size): hardware deals consecutive workgroup ids
+// round-robin over the 8 XCDs, so ids b and b+8 share an L2.  Returns a logical id such that logical
+// neighbours (which share input tiles / weights) run on the same XCD.  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7u, xcd = id & 7u, idx = id >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ---- 16-channel-granular kernels (conv_narrow.hip)
+extern "C" int dt_conv2d_n16_supported(const dt_conv_desc* d);
+int dt_conv2d_n16_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
+                         hipStream_t st);
+extern "C" int dt_conv2d_wgrad_n16_supported(const dt_conv_desc* d);
+int dt_wgrad_n16_cfg(const dt_conv_desc* d, int* ksplit, int* parts);
+int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* dy, float* ws, hipStream_t st);

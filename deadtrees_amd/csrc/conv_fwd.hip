@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
   float* lds_w = lds + IN_ELEMS;
   static_assert((IN_ELEMS & 3) == 0, "weight region must stay 16-byte aligned");
 
-  const int wg = blockIdx.x;
+  const int wg = (int)xcd_remap(blockIdx.x, gridDim.x);   // n-tiles of one spatial tile share an XCD's L2
   const int nt = wg % a.n_tiles;
   const int sp = wg / a.n_tiles;
   const int tx = sp % a.tiles_x;
@@ -436,6 +436,7 @@ extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* 
   DT_REQUIRE(src0 && w && out0, "conv: null pointer");
   DT_REQUIRE(d->C1 == 0 || src1, "conv: src1 missing");
   DT_REQUIRE(d->cout_split == 0 || out1, "conv: out1 missing");
+  if (dt_conv2d_n16_supported(d)) return dt_conv2d_n16_launch(d, src0, w, out0, stats, (hipStream_t)stream);
   ConvCfg c = pick_cfg(d);
   ConvArgs a;
   a.src0 = src0; a.src1 = src1; a.w = w; a.out0 = out0; a.out1 = out1; a.stats = stats;
@@ -496,6 +497,12 @@ extern "C" int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck
   int rc = validate(d);
   if (rc != DT_OK) return rc;
   ConvCfg c = pick_cfg(d);
+  if (dt_conv2d_n16_supported(d)) {   // conv_fwd_n16_kernel: 8x32 pixel tile, 16 output channels, CK 16
+    if (tw) *tw = 32;
+    if (tn) *tn = 16;
+    if (ck) *ck = 16;
+    return DT_OK;
+  }
   if (tw) *tw = c.tw;
   if (tn) *tn = d->ksize == 7 ? 64 : c.tn;
   if (ck) *ck = d->ksize == 7 ? 4 : ((d->ksize == 3 && (d->stride == 2 || d->C0 + d->C1 <= 32)) ? 8 : 16);

@@ -45,8 +45,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   float* lx = lds;
   float* ly = lds + X_ELEMS;
 
-  const int blk = blockIdx.x % (a.ci_blocks * a.co_blocks);
-  const int ks = blockIdx.x / (a.ci_blocks * a.co_blocks);
+  const int wgid = (int)xcd_remap(blockIdx.x, gridDim.x);  // (ci,co) blocks of one k-split share an XCD's L2
+  const int blk = wgid % (a.ci_blocks * a.co_blocks);
+  const int ks = wgid / (a.ci_blocks * a.co_blocks);
   const int cib = blk / a.co_blocks, cob = blk % a.co_blocks;
   const int ci0 = cib * CIW, co0 = cob * COW;
   const int Cin = a.C0 + a.C1;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem_kernel(const WgradArgs
 struct WgCfg {
   int tw, tpx, wci, wco, wk, ksplit, parts, T, tiles_x, tiles_y, ci_blocks, co_blocks;
   int rb, parts2;  // first reduction stage: blocks of rb slabs -> parts2 slabs (parts2 == parts: single stage)
-  bool stem;
+  bool stem, narrow;
 };
 
 static int wg_validate(const dt_conv_desc* d) {
@@ -281,6 +282,19 @@ static WgCfg wg_cfg(const dt_conv_desc* d) {
   WgCfg c;
   const int Cin = d->C0 + d->C1;
   c.stem = d->ksize == 7;
+  c.narrow = dt_conv2d_wgrad_n16_supported(d) != 0;
+  if (c.narrow) {
+    c.tw = 32; c.tpx = 128; c.wci = c.wco = 1; c.wk = 4; c.ci_blocks = c.co_blocks = 1;
+    c.tiles_x = c.tiles_y = 0;
+    c.T = dt_wgrad_n16_cfg(d, &c.ksplit, &c.parts);
+    c.rb = 1;
+    c.parts2 = c.parts;
+    if (c.parts > 16) {
+      c.rb = dt_cdiv(c.parts, 16);
+      c.parts2 = dt_cdiv(c.parts, c.rb);
+    }
+    return c;
+  }
   if (c.stem) {
     c.tw = STEM_TW; c.tpx = STEM_TW * STEM_TH; c.wci = 1; c.wco = 2; c.wk = 2;
     c.ci_blocks = 1; c.co_blocks = dt_cdiv(d->Cout, 64);
@@ -357,7 +371,9 @@ extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const f
   a.ci_blocks = c.ci_blocks; a.co_blocks = c.co_blocks; a.ksplit = c.ksplit;
   hipStream_t st = (hipStream_t)stream;
   const int grid = c.ci_blocks * c.co_blocks * c.ksplit;
-  if (c.stem) {
+  if (c.narrow) {
+    rc = dt_wgrad_n16_launch(d, src0, dy, workspace, st);
+  } else if (c.stem) {
     hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(grid), dim3(256), 0, st, a);
     DT_LAUNCH_CHECK();
   } else if (d->ksize == 3 && d->stride == 1) {

@@ -83,7 +83,12 @@ class UNetEngine:
             flops = 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout * desc.Ho * desc.Wo * desc.B
             if desc.mode0 == 2:
                 flops /= 4.0   # transposed conv: 3/4 of the zero-inserted input does no algorithmic work
-            prof.append((self._conv_kernel_name(desc), flops, e0, e1))
+            # algorithmic HBM bytes: stored input(s) once + output once (+ read-modify-write) + weights once
+            sdiv = 4 if desc.mode0 else 1
+            nbytes = 4.0 * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
+                                     desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
+                4.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
+            prof.append((self._conv_kernel_name(desc), flops, e0, e1, nbytes))
 
     # ------------------------------------------------------------------ forward units
     def _conv_bn(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, training):

@@ -44,6 +44,8 @@ CONV_CASES = [
     (2, 64, 96, 3, 64, 7, 2, 3),      # stem
     (1, 32, 32, 4, 64, 7, 2, 3),      # stem, RGBN
     (1, 34, 70, 512, 64, 3, 1, 1),    # many input chunks, width > 2 tiles
+    (2, 48, 80, 32, 16, 3, 1, 1),     # dec.4.conv1 shape: 16-wide MFMA kernel, two input chunks
+    (1, 24, 40, 8, 12, 3, 1, 1),      # 16-wide kernel with ragged channel counts
 ]
 
 
@@ -101,6 +103,21 @@ def test_conv_dgrad_stride2_via_zero_insert(Cin, Cout, k, p):
     assert rel_err(to_nchw(dx), x.grad) < 2e-6
 
 
+def test_conv_n16_with_virtual_upsample():
+    """dec.4.conv1: nearest x2 upsample (no skip) feeding the 16-output-channel kernel, with BN statistics"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    B, h, w_, Cin, Cout = 2, 20, 24, 32, 16
+    a = torch.randn((B, Cin, h, w_), generator=g)
+    wt = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.08
+    ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest").double(), wt.double(), padding=1)
+    y, _, stats = ops.conv2d(nhwc(a), hwio(wt), 3, 1, 1, mode0=1, want_stats=True)
+    assert rel_err(to_nchw(y), ref) < 2e-6
+    np.testing.assert_allclose(stats[0].double().sum(0).cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-5,
+                               atol=1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max()))
+    np.testing.assert_allclose(stats[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-5)
+
+
 def test_conv_dgrad_stride1():
     ops = _ops()
     g = torch.Generator().manual_seed(12)
@@ -125,6 +142,8 @@ WGRAD_CASES = [
     (2, 32, 32, 64, 128, 1, 2, 0),
     (2, 64, 96, 3, 64, 7, 2, 3),
     (1, 32, 32, 4, 64, 7, 2, 3),
+    (2, 36, 72, 16, 32, 3, 1, 1),     # 16-granular weight-gradient kernel, (1,2) tile arrangement
+    (1, 20, 44, 12, 8, 3, 1, 1),
 ]
 
 
