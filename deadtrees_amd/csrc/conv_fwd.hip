@@ -158,10 +158,58 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ lds_in, cons
   }
 }
 
+// zero-insertion variant: per row-tile tap mask (wave-uniform), B fragments re-read per tile
+template <int KS, int TN, int CK, int PLANE, int HALO_W>
+__device__ __forceinline__ void mma_chunk_zi(const float* __restrict__ lds_in, const float* __restrict__ lds_w,
+                                             const int (&abase)[2], int bbase, f32x16 (&acc)[2][TN / 32], int wave,
+                                             int pad) {
+  constexpr int NT = TN / 32;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int py = mt, px = (wave & 1) ? (1 - mt) : mt;
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      const int kh = tap / KS, kw = tap % KS;
+      if ((((py + kh - pad) | (px + kw - pad)) & 1) != 0) continue;   // structurally zero input: skip the tap
+#pragma unroll
+      for (int kk = 0; kk < CK / 2; ++kk) {
+        const float av = lds_in[abase[mt] + 2 * kk * PLANE + kh * HALO_W + kw];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float bv = lds_w[bbase + (tap * CK + 2 * kk) * TN + 32 * j];
+          acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mt][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
 // narrow-input stride-1 layers (Cin <= 32: one or two chunks, no pipelining depth) run the CK=8 variant at
 // 3 waves/SIMD; everything else 2 waves/SIMD (measured per layer with scripts/bench_conv.py)
-template <int KS, int STRIDE, int TW, int TN, int CK>
+// Zero-insertion (transposed-conv) tiles, ZI = true: 3/4 of the zero-inserted input is structurally zero, so an
+// output pixel of parity class (py,px) only sees the taps with (py+kh-pad, px+kw-pad) both even: 1/2/2/4 of the
+// 9 taps (1x1: only the even/even class).  Each 32-pixel MFMA row tile is therefore built from pixels of ONE
+// parity class (2 rows of the same parity x 16 same-parity columns) and skips the dead taps with wave-uniform
+// branches; every wave gets one light and one heavy class (5 or 4 taps instead of 18).
+template <bool ZI, int TW>
+__device__ __forceinline__ void tile_pixel(int wave, int mt, int m, int& row, int& col, int& py, int& px) {
+  if constexpr (ZI) {
+    const int pair = wave >> 1;
+    py = mt;                                  // wave's tile 0: even rows, tile 1: odd rows
+    px = (wave & 1) ? (1 - mt) : mt;          // even waves: (E,E)+(O,O); odd waves: (E,O)+(O,E)
+    row = py + 2 * (2 * pair + (m >> 4));
+    col = px + 2 * (m & 15);
+  } else {
+    const int p = (wave * 2 + mt) * 32 + m;
+    row = p / TW;
+    col = p % TW;
+    py = px = 0;
+  }
+}
+
+template <int KS, int STRIDE, int TW, int TN, int CK, bool ZI = false>
 __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) void conv_fwd_kernel(const ConvArgs a) {
+  static_assert(!ZI || (TW == 32 && STRIDE == 1), "zero-insertion tiles are 8 x 32");
   using G = ConvGeom<KS, STRIDE, TW, CK>;
   constexpr int NT = TN / 32;
   constexpr int IN_ELEMS = CK * G::PLANE;
@@ -186,8 +234,8 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
   int abase[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    const int p = (wave * 2 + mt) * 32 + r;
-    const int py = p / TW, px = p % TW;
+    int py, px, cy, cx;
+    tile_pixel<ZI, TW>(wave, mt, r, py, px, cy, cx);
     abase[mt] = s * G::PLANE + py * G::LS * G::HALO_W + px * G::LS;
   }
   const int bbase = s * TN + r;
@@ -202,14 +250,45 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
 
   const int Cin = a.C0 + a.C1;
   if constexpr (KS == 7) {
-    // stem (Cin = 3/4: scalar staging, a single chunk): synchronous fill
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
-      __syncthreads();
-      fill_input_planar<KS, STRIDE, TW, CK>(lds_in, a, b, iy0, ix0, c0);
-      fill_weights<G::TAPS, CK, TN>(lds_w, a.w, Cin, a.Cout, c0, n0);
-      __syncthreads();
-      mma_chunk<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
+    // stem (Cin = 3 or 4, a single chunk): scalar staging, but with every load of the tile in flight at once
+    constexpr int IN_TOTAL = G::HALO_H * G::HALO_W * CK;
+    constexpr int IN_IT = (IN_TOTAL + 255) / 256;
+    constexpr int W_TOTAL = G::TAPS * CK * TN;
+    constexpr int W_IT = (W_TOTAL + 255) / 256;
+    const int tid = threadIdx.x;
+    float rin[IN_IT], rw[W_IT];
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int c = idx % CK, pix = idx / CK;
+      const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
+      const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
+      float v = 0.f;
+      if (idx < IN_TOTAL && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && c < Cin)
+        v = a.src0[(((size_t)b * a.Hin + iy) * a.Win + ix) * Cin + c];
+      rin[it] = v;
     }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int n = idx % TN, row = idx / TN;
+      const int tap = row / CK, k = row - tap * CK;
+      float v = 0.f;
+      if (idx < W_TOTAL && k < Cin && n0 + n < a.Cout) v = a.w[((size_t)tap * Cin + k) * a.Cout + n0 + n];
+      rw[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < IN_TOTAL) lds_in[(idx % CK) * G::PLANE + idx / CK] = rin[it];
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < W_TOTAL) lds_w[idx] = rw[it];
+    }
+    __syncthreads();
+    mma_chunk<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
   } else {
     // Software-pipelined staging: the global loads of chunk c+1 are issued (into registers) before the
     // MFMAs of chunk c and written to LDS after them, so HBM/L2 latency hides under the matrix work.
@@ -289,7 +368,10 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
       write_lds();
       __syncthreads();
       if (c0 + CK < Cin) issue_loads(c0 + CK);
-      mma_chunk<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
+      if constexpr (ZI)
+        mma_chunk_zi<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc, wave, a.pad);
+      else
+        mma_chunk<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
     }
   }
 
@@ -316,9 +398,10 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
       bool ok[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * s;
-        const int p = (wave * 2 + mt) * 32 + row;
-        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        const int mrow = (i & 3) + 8 * (i >> 2) + 4 * s;
+        int ty_, tx_, cy, cx;
+        tile_pixel<ZI, TW>(wave, mt, mrow, ty_, tx_, cy, cx);
+        const int oy = oy0 + ty_, ox = ox0 + tx_;
         ok[i] = nok && oy < a.Ho && ox < a.Wo;
         off[i] = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld + nn;
       }
@@ -409,10 +492,10 @@ extern "C" int dt_conv2d_stat_rows(const dt_conv_desc* d) {
   return d->B * dt_cdiv(d->Ho, 256 / c.tw) * dt_cdiv(d->Wo, c.tw);
 }
 
-template <int KS, int STRIDE, int TW, int TN, int CK>
+template <int KS, int STRIDE, int TW, int TN, int CK, bool ZI = false>
 static int launch(const ConvArgs& a, hipStream_t st) {
   const long grid = (long)a.P * a.n_tiles;
-  hipLaunchKernelGGL((conv_fwd_kernel<KS, STRIDE, TW, TN, CK>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_fwd_kernel<KS, STRIDE, TW, TN, CK, ZI>), dim3((unsigned)grid), dim3(256), 0, st, a);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -448,6 +531,10 @@ extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* 
   a.n_tiles = dt_cdiv(d->Cout, c.tn);
   a.P = d->B * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
+  if (d->mode0 == 2 && d->stride == 1 && c.tw == 32 && d->C0 > 32) {   // transposed conv: parity-class tiles
+    if (d->ksize == 3) return c.tn == 64 ? launch<3, 1, 32, 64, 16, true>(a, st) : launch<3, 1, 32, 32, 16, true>(a, st);
+    if (d->ksize == 1) return c.tn == 64 ? launch<1, 1, 32, 64, 16, true>(a, st) : launch<1, 1, 32, 32, 16, true>(a, st);
+  }
   if (d->ksize == 3 && d->stride == 1)
     return (d->C0 + d->C1 <= 32) ? launch_tw_tn<3, 1, 8>(a, c, st) : launch_tw_tn<3, 1, 16>(a, c, st);
   if (d->ksize == 3 && d->stride == 2) return launch_tw_tn<3, 2, 8>(a, c, st);

@@ -206,24 +206,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem_kernel(const WgradArgs
     const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * 2 - a.pad, ix0 = ox0 * 2 - a.pad;
-    __syncthreads();
-    for (int idx = tid; idx < HALO_H * HALO_W * 4 + 32; idx += 256) {
+    // batched staging: all loads of the tile in flight before the first LDS write
+    constexpr int XT = HALO_H * HALO_W * 4 + 32, X_IT = (XT + 255) / 256;
+    constexpr int YT = TH * TW * (COW / 4), Y_IT = (YT + 255) / 256;
+    float rx[X_IT];
+    f32x4 ry[Y_IT];
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int idx = tid + it * 256;
       const int c = idx & 3, pix = idx >> 2;
       const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
       const int iy = iy0 + hy, ix = ix0 + hx;
       float v = 0.f;
       if (pix < HALO_H * HALO_W && c < Cin && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
         v = a.src0[(((size_t)b * a.Hin + iy) * a.Win + ix) * Cin + c];
-      lx[idx] = v;
+      rx[it] = v;
     }
-    for (int idx = tid; idx < TH * TW * (COW / 4); idx += 256) {
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int idx = tid + it * 256;
       const int q = idx % (COW / 4), pix = idx / (COW / 4);
       const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
       const int c = co0 + 4 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (oy < a.Ho && ox < a.Wo && c < a.Cout)
+      if (idx < YT && oy < a.Ho && ox < a.Wo && c < a.Cout)
         v = *reinterpret_cast<const f32x4*>(a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + c);
-      *reinterpret_cast<f32x4*>(ly + pix * COW + 4 * q) = v;
+      ry[it] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < XT) lx[idx] = rx[it];
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < YT) *reinterpret_cast<f32x4*>(ly + (idx / (COW / 4)) * COW + 4 * (idx % (COW / 4))) = ry[it];
     }
     __syncthreads();
 #pragma unroll

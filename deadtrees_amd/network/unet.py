@@ -399,7 +399,8 @@ class _UNetFunction(torch.autograd.Function):
         m = ctx.module
         grads = m._grad_buffer()
         m.engine.backward(dlogits, m.flat_params.detach(), grads)
-        return None, grads, None
+        # a trainer that consumes the flat buffer directly (HipTrainer) opts out of autograd's copy into .grad
+        return None, (grads if m.deliver_grad_to_autograd else None), None
 
 
 class UNetHIP(nn.Module):
@@ -423,6 +424,7 @@ class UNetHIP(nn.Module):
                              persistent=False)
         self._engine: Optional[UNetEngine] = None
         self._grads: Optional[torch.Tensor] = None
+        self.deliver_grad_to_autograd = True
         self.reset_parameters()
 
     # ------------------------------------------------------------------ init / state_dict

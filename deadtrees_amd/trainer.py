@@ -51,6 +51,7 @@ class HipTrainer:
         if not model.flat_params.is_cuda:
             raise RuntimeError("HipTrainer needs the model on an MI355X (model.to('cuda'))")
         self.model = model
+        model.deliver_grad_to_autograd = False   # this trainer reads the engine's flat gradient buffer itself
         self.losses = tuple(losses)
         self.opt = FlatAdam(model.flat_params.data, lr=lr, max_norm=clip)
         self.reducer = GradReducer(group) if distributed else None
