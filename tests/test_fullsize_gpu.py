@@ -1,0 +1,68 @@
+"""BASELINE-size checks (B=32, 512x512) through size-independent properties — the oracle is too slow here.
+
+* run-to-run determinism of a full training step (no float atomics anywhere: fixed-order reductions),
+* eval-mode batch independence: forward of a batch == concatenation of the forwards of its halves (bit-exact),
+* fused uint8/int64 argmax == argmax of the emitted logits, ties to the lowest index,
+* loss sums are additive over batch halves (GDICE counts / F-score sums), i.e. the fused reduction sees every pixel once.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B, S = 32, 512
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from deadtrees_amd.data.synthetic import synth_batch
+    img, mask = synth_batch(B, S, S, 3, 2, seed=1234)
+    return img.to(DEV), mask.to(DEV)
+
+
+def _model(seed=0):
+    from deadtrees_amd.network.unet import UNetHIP
+    m = UNetHIP()
+    m.reset_parameters(seed=seed)
+    return m.to(DEV)
+
+
+def test_training_step_is_bitwise_deterministic(batch):
+    from deadtrees_amd.trainer import HipTrainer
+    img, mask = batch
+    outs = []
+    for _ in range(2):
+        m = _model()
+        tr = HipTrainer(m)
+        loss = tr.step(img, mask)
+        outs.append((loss.clone(), m._grad_buffer().clone(), m.flat_params.detach().clone(), m.bn_state.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0]) and float(outs[0][1].abs().max()) > 0
+
+
+def test_eval_forward_is_batch_independent_and_argmax_is_fused(batch):
+    img, _ = batch
+    m = _model().eval()
+    with torch.no_grad():
+        full = m(img)
+        halves = torch.cat([m(img[:16]), m(img[16:])])
+    assert torch.equal(full, halves)
+    am8 = m.predict_classes(img, dtype="uint8")
+    am64 = m.predict_classes(img, dtype="int64")
+    assert am8.dtype == torch.uint8 and am64.dtype == torch.int64
+    assert torch.equal(am64, full.argmax(dim=1)) and torch.equal(am8.long(), am64)
+
+
+def test_loss_sums_are_additive_over_the_batch(batch):
+    from deadtrees_amd.loss.seg_loss import loss_sums
+    img, mask = batch
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn((B, 2, S, S), generator=g) * 2).to(DEV)
+    acc, _, err = loss_sums(logits, mask)
+    a0, _, _ = loss_sums(logits[:16].contiguous(), mask[:16].contiguous())
+    a1, _, _ = loss_sums(logits[16:].contiguous(), mask[16:].contiguous())
+    assert int(err) == 0
+    assert torch.equal(acc, torch.cat([a0, a1]))                      # per-sample rows: identical arithmetic
+    assert float(acc[..., 0].sum()) == B * S * S                      # every pixel counted exactly once
+    assert float(acc[:, 1, 0].sum()) == float((mask == 1).sum())
