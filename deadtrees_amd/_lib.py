@@ -30,20 +30,20 @@ SIGNATURES = {
     "dt_version": (C.c_int, []),
     "dt_device_count": (C.c_int, []),
     "dt_conv2d_stat_rows": (C.c_int, [_P]),
-    "dt_conv2d": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "dt_conv2d": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_config": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dt_weight_flip_transpose": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),
-    "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f]),
+    "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),
     "dt_bn_stats_floats": (I64, [C.c_int, C.c_int]),
     "dt_bn_bwd_red_floats": (I64, [I64, C.c_int]),
     "dt_bn_finalize": (C.c_int, [c_f, C.c_int, C.c_int, F64, c_f, c_f, F32, F32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_bn_eval_affine": (C.c_int, [c_f, c_f, c_f, c_f, F32, C.c_int, c_f, c_f, c_f]),
     "dt_bn_act": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, C.c_int, c_f]),
     "dt_bn_bwd_rows": (C.c_int, [I64, C.c_int]),
-    "dt_bn_bwd_reduce": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, c_f]),
-    "dt_bn_bwd_apply": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int, I64,
-                                  C.c_int, c_f]),
+    "dt_bn_bwd_reduce": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, c_f]),
+    "dt_bn_bwd_apply": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int,
+                                  I64, C.c_int, c_f]),
     "dt_maxpool3x3s2": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_maxpool3x3s2_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_upsample2x_bwd": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

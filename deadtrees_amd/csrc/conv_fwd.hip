@@ -22,6 +22,8 @@ struct ConvArgs {
   const float* src0;
   const float* src1;
   const float* w;
+  const float* in_scale;  // optional per-channel affine + ReLU applied to source 0 while staging (fused BatchNorm
+  const float* in_shift;  // apply of the producer layer: z = relu(y*scale+shift) is never materialised)
   float* out0;
   float* out1;
   float* stats;
@@ -207,9 +209,20 @@ __device__ __forceinline__ void tile_pixel(int wave, int mt, int m, int& row, in
   }
 }
 
-template <int KS, int STRIDE, int TW, int TN, int CK, bool ZI = false>
+#define DT_TF_MAXC 512   // channels of source 0 that may carry a fused input transform
+
+template <int KS, int STRIDE, int TW, int TN, int CK, bool ZI = false, bool TF = false>
 __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) void conv_fwd_kernel(const ConvArgs a) {
   static_assert(!ZI || (TW == 32 && STRIDE == 1), "zero-insertion tiles are 8 x 32");
+  static_assert(!TF || (KS != 7 && !ZI), "input transform: regular tiles only");
+  // TF: per-channel scale/shift of source 0 live in LDS (no registers held across the MFMA loop)
+  __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 2 * DT_TF_MAXC : 4];
+  if constexpr (TF) {
+    for (int i = threadIdx.x; i < a.C0; i += 256) {
+      lds_tf[i] = a.in_scale[i];
+      lds_tf[DT_TF_MAXC + i] = a.in_shift[i];
+    }
+  }
   using G = ConvGeom<KS, STRIDE, TW, CK>;
   constexpr int NT = TN / 32;
   constexpr int IN_ELEMS = CK * G::PLANE;
@@ -329,6 +342,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
       const float* src = use0 ? a.src0 : a.src1;
       const int C = use0 ? a.C0 : a.C1;
       const int cc = (use0 ? c0 : c0 - a.C0) + 4 * qi;
+
 #pragma unroll
       for (int it = 0; it < IN_IT; ++it) {
         const int p = use0 ? pidx0[it] : pidx1[it];
@@ -344,16 +358,32 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
         rw[it] = v;
       }
     };
-    auto write_lds = [&]() {
+    auto write_lds = [&](int c0) {
+      bool tf_on = false;
+      f32x4 tf_sc = {1.f, 1.f, 1.f, 1.f}, tf_sh = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (TF) {
+        const int cc = c0 + 4 * qi;
+        tf_on = cc < a.C0;
+        if (tf_on) {
+          tf_sc = *reinterpret_cast<const f32x4*>(lds_tf + cc);
+          tf_sh = *reinterpret_cast<const f32x4*>(lds_tf + DT_TF_MAXC + cc);
+        }
+      }
 #pragma unroll
       for (int it = 0; it < IN_IT; ++it) {
         const int pix = pix0 + it * (256 / QI);
         if (IN_TOTAL % 256 == 0 || pix < G::HALO_H * G::HALO_W) {
+          f32x4 v = rin[it];
+          if (TF && tf_on && pidx0[it] >= 0) {   // zero padding stays zero: only real pixels get the affine + ReLU
+            v = v * tf_sc + tf_sh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+          }
           float* d = lds_in + (4 * qi) * G::PLANE + pix;
-          d[0] = rin[it][0];
-          d[G::PLANE] = rin[it][1];
-          d[2 * G::PLANE] = rin[it][2];
-          d[3 * G::PLANE] = rin[it][3];
+          d[0] = v[0];
+          d[G::PLANE] = v[1];
+          d[2 * G::PLANE] = v[2];
+          d[3 * G::PLANE] = v[3];
         }
       }
 #pragma unroll
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
     issue_loads(0);
     for (int c0 = 0; c0 < Cin; c0 += CK) {
       __syncthreads();   // every wave is done reading the previous chunk
-      write_lds();
+      write_lds(c0);
       __syncthreads();
       if (c0 + CK < Cin) issue_loads(c0 + CK);
       if constexpr (ZI)
@@ -495,6 +525,18 @@ extern "C" int dt_conv2d_stat_rows(const dt_conv_desc* d) {
 template <int KS, int STRIDE, int TW, int TN, int CK, bool ZI = false>
 static int launch(const ConvArgs& a, hipStream_t st) {
   const long grid = (long)a.P * a.n_tiles;
+  if constexpr (KS == 3 && STRIDE == 1 && !ZI) {
+    if (a.in_scale != nullptr) {
+      hipLaunchKernelGGL((conv_fwd_kernel<KS, STRIDE, TW, TN, CK, false, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+      DT_LAUNCH_CHECK();
+      return DT_OK;
+    }
+  } else {
+    if (a.in_scale != nullptr) {
+      dt_set_error("conv: fused input transform is only built for 3x3 stride-1 layers");
+      return DT_ENOSYS;
+    }
+  }
   hipLaunchKernelGGL((conv_fwd_kernel<KS, STRIDE, TW, TN, CK, ZI>), dim3((unsigned)grid), dim3(256), 0, st, a);
   DT_LAUNCH_CHECK();
   return DT_OK;
@@ -513,16 +555,22 @@ static int launch_tw_tn(const ConvArgs& a, const ConvCfg& c, hipStream_t st) {
 }
 
 extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const float* w,
-                         float* out0, float* out1, float* stats, void* stream) {
+                         float* out0, float* out1, float* stats, const float* in_scale, const float* in_shift,
+                         void* stream) {
   int rc = validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && w && out0, "conv: null pointer");
   DT_REQUIRE(d->C1 == 0 || src1, "conv: src1 missing");
   DT_REQUIRE(d->cout_split == 0 || out1, "conv: out1 missing");
-  if (dt_conv2d_n16_supported(d)) return dt_conv2d_n16_launch(d, src0, w, out0, stats, (hipStream_t)stream);
+  DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv: in_scale/in_shift must come together");
+  DT_REQUIRE(in_scale == nullptr || (d->ksize == 3 && d->stride == 1 && d->mode0 != 2 && d->C0 <= DT_TF_MAXC),
+             "conv: input transform needs a 3x3 stride-1 layer with C0 <= %d and no zero-insertion", DT_TF_MAXC);
+  if (dt_conv2d_n16_supported(d))
+    return dt_conv2d_n16_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream);
   ConvCfg c = pick_cfg(d);
   ConvArgs a;
   a.src0 = src0; a.src1 = src1; a.w = w; a.out0 = out0; a.out1 = out1; a.stats = stats;
+  a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.cout_split = d->cout_split; a.pad = d->pad;
   a.accumulate = d->accumulate;

@@ -13,6 +13,8 @@
 
 struct NarrowArgs {
   const float* src0;
+  const float* in_scale;  // optional fused BatchNorm-apply + ReLU of the producer layer (see conv_fwd.hip)
+  const float* in_shift;
   const float* w;      // [9][Cin][Cout]
   float* out;
   float* stats;        // [2][P][Cout] or null
@@ -95,11 +97,18 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_n16_kernel(const NarrowArgs a
     for (int it = 0; it < IN_IT; ++it) {
       const int pix = pix0 + it * 64;
       if (pix < N16_HH * N16_HW) {
+        f32x4 v = rin[it];
+        if (a.in_scale != nullptr && pidx[it] >= 0 && c0 + 4 * qi < a.Cin) {
+          v = v * *reinterpret_cast<const f32x4*>(a.in_scale + c0 + 4 * qi) +
+              *reinterpret_cast<const f32x4*>(a.in_shift + c0 + 4 * qi);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+        }
         float* d = lds_in + lds_q_base + pix;
-        d[0] = rin[it][0];
-        d[N16_PLANE] = rin[it][1];
-        d[2 * N16_PLANE] = rin[it][2];
-        d[3 * N16_PLANE] = rin[it][3];
+        d[0] = v[0];
+        d[N16_PLANE] = v[1];
+        d[2 * N16_PLANE] = v[2];
+        d[3 * N16_PLANE] = v[3];
       }
     }
 #pragma unroll
@@ -170,9 +179,9 @@ extern "C" int dt_conv2d_n16_supported(const dt_conv_desc* d) {
 int dt_conv2d_n16_rows(const dt_conv_desc* d) { return d->B * dt_cdiv(d->Ho, N16_TH) * dt_cdiv(d->Wo, N16_TW); }
 
 int dt_conv2d_n16_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
-                         hipStream_t st) {
+                         const float* in_scale, const float* in_shift, hipStream_t st) {
   NarrowArgs a;
-  a.src0 = src0; a.w = w; a.out = out; a.stats = stats;
+  a.src0 = src0; a.w = w; a.out = out; a.stats = stats; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->C0; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.tiles_x = dt_cdiv(d->Wo, N16_TW); a.tiles_y = dt_cdiv(d->Ho, N16_TH);
@@ -186,6 +195,8 @@ int dt_conv2d_n16_launch(const dt_conv_desc* d, const float* src0, const float* 
 // M = 16 input channels, N = 16 output channels, K = 4 pixels per MFMA; one accumulator per (tap, ci-tile, co-tile).
 struct NarrowWgArgs {
   const float* src0;
+  const float* in_scale;
+  const float* in_shift;
   const float* dy;
   float* ws;           // [parts][9][Cin][Cout]
   int B, Hin, Win, Cin, mode0, Ho, Wo, Cout, tiles_x, tiles_y, T, ksplit;
@@ -218,6 +229,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_n16_kernel(const NarrowWgAr
   constexpr int Y_TOTAL = W16_TH * W16_TW * QY, Y_IT = (Y_TOTAL + 255) / 256;
   const int qx = tid % QX, px0 = tid / QX, qy = tid % QY, py0 = tid / QY;
   const int Hs = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws = a.mode0 ? (a.Win >> 1) : a.Win;
+  f32x4 x_sc = {1.f, 1.f, 1.f, 1.f}, x_sh = {0.f, 0.f, 0.f, 0.f};
+  if (a.in_scale != nullptr && 4 * qx < a.Cin) {
+    x_sc = *reinterpret_cast<const f32x4*>(a.in_scale + 4 * qx);
+    x_sh = *reinterpret_cast<const f32x4*>(a.in_shift + 4 * qx);
+  }
   const int xb = wave * W16_HW * CIW + kq * CIW + m;   // row `wave` of the tile, pixel kq of the 4-pixel k-step
   const int yb = wave * W16_TW * COW + kq * COW + m;
 
@@ -226,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_n16_kernel(const NarrowWgAr
     const int oy0 = ty * W16_TH, ox0 = tx * W16_TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     f32x4 rx[X_IT], ry[Y_IT];
+    unsigned xvalid = 0;
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
       const int pix = px0 + it * (256 / QX);
@@ -235,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_n16_kernel(const NarrowWgAr
       if (pix < W16_HH * W16_HW && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && 4 * qx < a.Cin) {
         const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
         v = *reinterpret_cast<const f32x4*>(a.src0 + (((size_t)b * Hs + sy) * Ws + sx) * a.Cin + 4 * qx);
+        xvalid |= 1u << it;
       }
       rx[it] = v;
     }
@@ -251,7 +269,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_n16_kernel(const NarrowWgAr
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
       const int pix = px0 + it * (256 / QX);
-      if (pix < W16_HH * W16_HW) *reinterpret_cast<f32x4*>(lx + pix * CIW + 4 * qx) = rx[it];
+      if (pix < W16_HH * W16_HW) {
+        f32x4 v = rx[it];
+        if (a.in_scale != nullptr && ((xvalid >> it) & 1u)) {   // fused BN-apply + ReLU; padding stays zero
+          v = v * x_sc + x_sh;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+        }
+        *reinterpret_cast<f32x4*>(lx + pix * CIW + 4 * qx) = v;
+      }
     }
 #pragma unroll
     for (int it = 0; it < Y_IT; ++it) {
@@ -310,9 +336,10 @@ int dt_wgrad_n16_cfg(const dt_conv_desc* d, int* ksplit, int* parts) {
   return T;
 }
 
-int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* dy, float* ws, hipStream_t st) {
+int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* dy, float* ws, const float* in_scale,
+                        const float* in_shift, hipStream_t st) {
   NarrowWgArgs a;
-  a.src0 = src0; a.dy = dy; a.ws = ws;
+  a.src0 = src0; a.dy = dy; a.ws = ws; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->C0; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.tiles_x = dt_cdiv(d->Wo, W16_TW); a.tiles_y = dt_cdiv(d->Ho, W16_TH);

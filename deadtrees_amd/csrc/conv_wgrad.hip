@@ -14,6 +14,8 @@
 struct WgradArgs {
   const float* src0;
   const float* src1;
+  const float* in_scale;  // optional fused BatchNorm-apply + ReLU on source 0 (see conv_fwd.hip)
+  const float* in_shift;
   const float* dy;
   float* ws;  // [parts][taps][Cin][Cout]
   int B, Hin, Win, C0, C1, mode0;
@@ -32,7 +34,7 @@ struct WGeom {
   static constexpr int TAPS = KS * KS;
 };
 
-template <int KS, int STRIDE, int TW, int TPX, int WCI, int WCO>
+template <int KS, int STRIDE, int TW, int TPX, int WCI, int WCO, bool TF = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   using G = WGeom<KS, STRIDE, TW, TPX>;
   constexpr int WK = 4 / (WCI * WCO);
@@ -83,6 +85,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const int xmode = x_use0 ? a.mode0 : 0;
   const int xHs = xmode ? (a.Hin >> 1) : a.Hin, xWs = xmode ? (a.Win >> 1) : a.Win;
   const bool x_ch_ok = cx < Cin;
+  // fused BatchNorm-apply + ReLU on source 0: scale/shift of this lane's channel quad parked in LDS so that no
+  // registers are held across the MFMA loop; applied when the staged registers are written to LDS
+  const bool x_tf = TF && x_use0 && x_ch_ok;
+  __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 2 * CIW : 4];
+  if (TF && tid < CIW && ci0 + tid < a.C0) {
+    lds_tf[tid] = a.in_scale[ci0 + tid];
+    lds_tf[CIW + tid] = a.in_shift[ci0 + tid];
+  }
+  unsigned xvalid = 0;
   const int cy = co0 + 4 * qy;
   const bool y_ch_ok = cy < a.Cout;
   f32x4 rx[X_IT], ry[Y_IT];
@@ -103,6 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       const int sy = xmode ? (iy >> 1) : iy, sx = xmode ? (ix >> 1) : ix;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) v = *reinterpret_cast<const f32x4*>(xsrc + (((size_t)b * xHs + sy) * xWs + sx) * xC + xcc);
+      if constexpr (TF) {
+        if (it == 0) xvalid = 0;
+        xvalid |= (ok ? 1u : 0u) << it;
+      }
       rx[it] = v;
     }
 #pragma unroll
@@ -116,10 +131,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
   };
   auto write_lds = [&]() {
+    f32x4 x_sc = {1.f, 1.f, 1.f, 1.f}, x_sh = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (TF) {
+      if (x_tf) {
+        x_sc = *reinterpret_cast<const f32x4*>(lds_tf + 4 * qx);
+        x_sh = *reinterpret_cast<const f32x4*>(lds_tf + CIW + 4 * qx);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
       const int pix = px0 + it * (256 / QX);
-      if (X_TOTAL % 256 == 0 || pix < G::HALO_H * G::HALO_W) *reinterpret_cast<f32x4*>(lx + pix * CIW + 4 * qx) = rx[it];
+      if (X_TOTAL % 256 == 0 || pix < G::HALO_H * G::HALO_W) {
+        f32x4 v = rx[it];
+        if (TF && x_tf && ((xvalid >> it) & 1u)) {   // padding stays zero
+          v = v * x_sc + x_sh;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+        }
+        *reinterpret_cast<f32x4*>(lx + pix * CIW + 4 * qx) = v;
+      }
     }
 #pragma unroll
     for (int it = 0; it < Y_IT; ++it) {
@@ -357,6 +387,13 @@ extern "C" size_t dt_conv2d_wgrad_workspace(const dt_conv_desc* d) {
 
 template <int KS, int STRIDE, int TW, int TPX, int WCI, int WCO>
 static int wg_launch(const WgradArgs& a, int grid, hipStream_t st) {
+  if constexpr (KS == 3 && STRIDE == 1) {
+    if (a.in_scale != nullptr) {
+      hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, TW, TPX, WCI, WCO, true>), dim3(grid), dim3(256), 0, st, a);
+      DT_LAUNCH_CHECK();
+      return DT_OK;
+    }
+  }
   hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, TW, TPX, WCI, WCO>), dim3(grid), dim3(256), 0, st, a);
   DT_LAUNCH_CHECK();
   return DT_OK;
@@ -372,7 +409,8 @@ static int wg_dispatch(const WgradArgs& a, const WgCfg& c, int grid, hipStream_t
 }
 
 extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy,
-                               float* dw, float* workspace, size_t workspace_bytes, void* stream) {
+                               float* dw, float* workspace, size_t workspace_bytes, const float* in_scale,
+                               const float* in_shift, void* stream) {
   int rc = wg_validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && dy && dw && workspace, "wgrad: null pointer");
@@ -383,7 +421,10 @@ extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const f
   DT_REQUIRE(workspace_bytes >= dt_conv2d_wgrad_workspace(d), "wgrad: workspace too small (%zu < %zu)",
              workspace_bytes, dt_conv2d_wgrad_workspace(d));
   WgradArgs a;
-  a.src0 = src0; a.src1 = src1; a.dy = dy; a.ws = workspace;
+  DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wgrad: in_scale/in_shift must come together");
+  DT_REQUIRE(in_scale == nullptr || (d->ksize == 3 && d->stride == 1 && d->mode0 != 2),
+             "wgrad: input transform needs a 3x3 stride-1 layer without zero-insertion");
+  a.src0 = src0; a.src1 = src1; a.dy = dy; a.ws = workspace; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.pad = d->pad;
   a.tiles_x = c.tiles_x; a.tiles_y = c.tiles_y; a.T = c.T;
@@ -391,7 +432,7 @@ extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const f
   hipStream_t st = (hipStream_t)stream;
   const int grid = c.ci_blocks * c.co_blocks * c.ksplit;
   if (c.narrow) {
-    rc = dt_wgrad_n16_launch(d, src0, dy, workspace, st);
+    rc = dt_wgrad_n16_launch(d, src0, dy, workspace, in_scale, in_shift, st);
   } else if (c.stem) {
     hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(grid), dim3(256), 0, st, a);
     DT_LAUNCH_CHECK();

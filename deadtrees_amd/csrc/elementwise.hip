@@ -208,6 +208,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restr
                                                             const f32x4* __restrict__ y,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
+                                                            const float* __restrict__ act_scale,
+                                                            const float* __restrict__ act_shift,
                                                             float* __restrict__ red, int64_t n_pix, int C4, int Q,
                                                             int P) {
   __shared__ f32x4 sh[2][256];
@@ -219,6 +221,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restr
   if (p1 > n_pix) p1 = n_pix;
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cq];
   const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cq];
+  // ReLU mask either from the stored activation or recomputed from y (virtual activation: z = relu(y*sc+sh))
+  const bool from_y = out_act == nullptr && act_scale != nullptr;
+  f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+  if (from_y) {
+    asc = reinterpret_cast<const f32x4*>(act_scale)[cq];
+    ash = reinterpret_cast<const f32x4*>(act_shift)[cq];
+  }
   f32x4 sg0 = {0.f, 0.f, 0.f, 0.f}, sx0 = sg0, sg1 = sg0, sx1 = sg0;
   int64_t p = p0 + rl;
   for (; p + RL < p1; p += 2 * RL) {
@@ -227,6 +236,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restr
     const f32x4 y0 = y[o0], y1 = y[o1];
     if (out_act) {
       const f32x4 a0 = out_act[o0], a1 = out_act[o1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g0[k] = a0[k] > 0.f ? g0[k] : 0.f;
+        g1[k] = a1[k] > 0.f ? g1[k] : 0.f;
+      }
+    } else if (from_y) {
+      const f32x4 a0 = y0 * asc + ash, a1 = y1 * asc + ash;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         g0[k] = a0[k] > 0.f ? g0[k] : 0.f;
@@ -241,6 +257,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restr
     f32x4 g0 = dout[o0];
     if (out_act) {
       const f32x4 a0 = out_act[o0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g0[k] = a0[k] > 0.f ? g0[k] : 0.f;
+    } else if (from_y) {
+      const f32x4 a0 = y[o0] * asc + ash;
 #pragma unroll
       for (int k = 0; k < 4; ++k) g0[k] = a0[k] > 0.f ? g0[k] : 0.f;
     }
@@ -261,7 +281,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restr
 }
 
 extern "C" int dt_bn_bwd_reduce(const float* dout, const float* out_act, const float* y, const float* mean,
-                                const float* invstd, float* red, int64_t n_pix, int C, void* stream) {
+                                const float* invstd, const float* act_scale, const float* act_shift, float* red,
+                                int64_t n_pix, int C, void* stream) {
   DT_REQUIRE(dout && y && mean && invstd && red && n_pix > 0 && C > 0 && (C & 3) == 0, "bn_bwd_reduce: bad args");
   const int C4 = C / 4;
   int Q = 64;
@@ -269,7 +290,7 @@ extern "C" int dt_bn_bwd_reduce(const float* dout, const float* out_act, const f
   DT_REQUIRE(C4 % Q == 0, "bn_bwd_reduce: C/4 must be a power of two or a multiple of 64 (C=%d)", C);
   const int P = dt_bn_bwd_rows(n_pix, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C4 / Q, P), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dout,
-                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, red, n_pix, C4, Q, P);
+                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, act_scale, act_shift, red, n_pix, C4, Q, P);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -303,14 +324,20 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4* __restrict__ dout, const f32x4* __restrict__ out_act, const f32x4* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ dgamma, const float* __restrict__ dbeta, f32x4* __restrict__ dy,
-    f32x4* __restrict__ dres, int dres_acc, int64_t n4, int C4, float inv_count) {
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta, const float* __restrict__ act_scale,
+    const float* __restrict__ act_shift, f32x4* __restrict__ dy, f32x4* __restrict__ dres, int dres_acc, int64_t n4,
+    int C4, float inv_count) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const int c4 = (int)(i % C4);
     f32x4 g = dout[i];
+    const f32x4 yv = y[i];
     if (out_act) {
       const f32x4 a = out_act[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+    } else if (act_scale) {
+      const f32x4 a = yv * reinterpret_cast<const f32x4*>(act_scale)[c4] + reinterpret_cast<const f32x4*>(act_shift)[c4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
     }
@@ -325,15 +352,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
     const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c4];
     const f32x4 db = reinterpret_cast<const f32x4*>(dbeta)[c4];
-    const f32x4 xh = (y[i] - mu) * is;
+    const f32x4 xh = (yv - mu) * is;
     dy[i] = ga * is * (g - db * inv_count - xh * (dg * inv_count));
   }
 }
 
 extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
-                               const float* invstd, const float* gamma, float* red, int P, float* dgamma,
-                               float* dbeta, float* dy, float* dres, int dres_accumulate, int64_t n_pix, int C,
-                               void* stream) {
+                               const float* invstd, const float* gamma, const float* act_scale,
+                               const float* act_shift, float* red, int P, float* dgamma, float* dbeta, float* dy,
+                               float* dres, int dres_accumulate, int64_t n_pix, int C, void* stream) {
   DT_REQUIRE(dout && y && mean && invstd && gamma && red && dgamma && dbeta && dy && n_pix > 0 && C > 0 &&
                  (C & 3) == 0 && P > 0,
              "bn_bwd_apply: bad args");
@@ -350,8 +377,8 @@ extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const fl
   DT_LAUNCH_CHECK();
   const int64_t n4 = n_pix * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, (const f32x4*)dout,
-                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, gamma, dgamma, dbeta, (f32x4*)dy,
-                     (f32x4*)dres, dres_accumulate, n4, C / 4, (float)(1.0 / (double)n_pix));
+                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, gamma, dgamma, dbeta, act_scale, act_shift,
+                     (f32x4*)dy, (f32x4*)dres, dres_accumulate, n4, C / 4, (float)(1.0 / (double)n_pix));
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -70,12 +70,13 @@ class UNetEngine:
         _lib.check(self.lib.dt_conv2d_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck)), "dt_conv2d_config")
         return f"conv_fwd_kernel<{desc.ksize},{desc.stride},{tw.value},{tn.value},{ck.value}>"
 
-    def _conv(self, desc, src0, src1, w, out0, out1=None, stats=None):
+    def _conv(self, desc, src0, src1, w, out0, out1=None, stats=None, in_ss=None):
         prof = self.profile
         if prof is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         _lib.check(self.lib.dt_conv2d(C.byref(desc), _p(src0), _p(src1), _p(w), _p(out0), _p(out1), _p(stats),
+                                      _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                       _stream()), "dt_conv2d")
         if prof is not None:
             e1 = torch.cuda.Event(enable_timing=True)
@@ -91,8 +92,15 @@ class UNetEngine:
             prof.append((self._conv_kernel_name(desc), flops, e0, e1, nbytes))
 
     # ------------------------------------------------------------------ forward units
-    def _conv_bn(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, training):
-        """y = conv(x); BN statistics -> per-channel scale/shift in bnws.  Returns y, (Ho, Wo)."""
+    def _ss(self, c: ConvSpec, bnws):
+        """(scale, shift) slices of conv c's BatchNorm in the per-forward workspace"""
+        nb = self.spec.n_bn_channels
+        return (bnws[2 * nb + c.bn_off: 2 * nb + c.bn_off + c.cout], bnws[3 * nb + c.bn_off: 3 * nb + c.bn_off + c.cout])
+
+    def _conv_bn(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, training, in_ss=None):
+        """y = conv(x); BN statistics -> per-channel scale/shift in bnws.  Returns y, (Ho, Wo).
+        in_ss: (scale, shift) of the layer that produced src0 when src0 is a RAW conv output whose
+        BatchNorm-apply + ReLU is fused into this conv's LDS staging (virtual activation)."""
         dev = src0.device
         Ho = (Hin + 2 * c.pad - c.k) // c.stride + 1
         Wo = (Win + 2 * c.pad - c.k) // c.stride + 1
@@ -116,12 +124,12 @@ class UNetEngine:
             if P <= 0:
                 raise RuntimeError(f"dt_conv2d_stat_rows: {self.lib.dt_last_error().decode()}")
             stats = self._buf("bn_stats", self.lib.dt_bn_stats_floats(P, c.cout), device=dev)
-            self._conv(desc, src0, src1, w, y, None, stats)
+            self._conv(desc, src0, src1, w, y, None, stats, in_ss)
             _lib.check(self.lib.dt_bn_finalize(_p(stats), P, c.cout, float(B * Ho * Wo), _p(gamma), _p(beta),
                                                BN_EPS, BN_MOMENTUM, _p(rmean), _p(rvar), _p(mean), _p(invstd),
                                                _p(scale), _p(shift), _stream()), "dt_bn_finalize")
         else:
-            self._conv(desc, src0, src1, w, y, None, None)
+            self._conv(desc, src0, src1, w, y, None, None, in_ss)
             _lib.check(self.lib.dt_bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), BN_EPS, c.cout,
                                                   _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
         return y, Ho, Wo, (scale, shift)
@@ -179,29 +187,37 @@ class UNetEngine:
             for bi, blk in enumerate(blocks):
                 xin = cur
                 y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw, training)
-                z1 = self._bn_act(y1, ss1)
-                y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, z1, None, 0, B, h1, w1, training)
+                # z1 = relu(bn1(y1)) is virtual: conv2 applies it while staging y1
+                y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
+                                                in_ss=ss1)
                 if blk.down is not None:
                     yd, _, _, ssd = self._conv_bn(blk.down, params, bnstate, bnws, xin, None, 0, B, ch, cw, training)
                     out = self._bn_act(y2, ss2, res=yd, res_ss=ssd)
                 else:
                     yd = None
                     out = self._bn_act(y2, ss2, res=xin)
-                keep(f"L{li}B{bi}", x=xin, y1=y1, z1=z1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
+                keep(f"L{li}B{bi}", x=xin, y1=y1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
                 cur, ch, cw = out, h2, w2
             feats.append(cur)
         # feats = [f1, f2, f3, f4, f5]
         d, dh, dw = feats[4], ch, cw
+        d_ss = None   # (scale, shift) when d is a raw conv output with a virtual activation
         skips = [feats[3], feats[2], feats[1], feats[0], None]
         for i, blk in enumerate(sp.decoder):
             skip = skips[i]
             Hin, Win = 2 * dh, 2 * dw
-            y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training)
-            z1 = self._bn_act(y1, ss1)
-            y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, z1, None, 0, B, h1, w1, training)
-            z2 = self._bn_act(y2, ss2)
-            keep(f"D{i}", x=d, skip=skip, y1=y1, z1=z1, y2=y2, z2=z2, H=h1, W=w1)
-            d, dh, dw = z2, h2, w2
+            y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training,
+                                            in_ss=d_ss)
+            y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
+                                            in_ss=ss1)
+            if i == len(sp.decoder) - 1:
+                z2 = self._bn_act(y2, ss2)      # the head kernel reads a materialised activation
+                nxt, nxt_ss = z2, None
+            else:
+                z2 = None                        # virtual: the next block's conv1 applies bn2+relu while staging
+                nxt, nxt_ss = y2, ss2
+            keep(f"D{i}", x=d, x_virtual=d_ss is not None, skip=skip, y1=y1, y2=y2, z2=z2, H=h1, W=w1)
+            d, dh, dw, d_ss = nxt, h2, w2, nxt_ss
 
         # ---- head
         hd = sp.head
@@ -223,7 +239,9 @@ class UNetEngine:
         return logits, (am64 if am64 is not None else am8)
 
     # ------------------------------------------------------------------ backward units
-    def _bn_bwd(self, c: ConvSpec, params, grads, bnws, dout, out_act, y, dres=None, dres_acc=False):
+    def _bn_bwd(self, c: ConvSpec, params, grads, bnws, dout, out_act, y, dres=None, dres_acc=False,
+                virtual_act=False):
+        """virtual_act: the activation was never stored; its ReLU mask is recomputed from y*scale+shift"""
         B, H, W, Cc = y.shape
         n_pix = B * H * W
         nb = self.spec.n_bn_channels
@@ -233,16 +251,18 @@ class UNetEngine:
         P = self.lib.dt_bn_bwd_rows(n_pix, Cc)
         red = self._buf("bn_red", self.lib.dt_bn_bwd_red_floats(n_pix, Cc), device=y.device)
         st = _stream()
-        _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(red), n_pix, Cc,
-                                             st), "dt_bn_bwd_reduce")
+        asc, ash = self._ss(c, bnws) if virtual_act else (None, None)
+        _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc), _p(ash),
+                                             _p(red), n_pix, Cc, st), "dt_bn_bwd_reduce")
         dy = torch.empty_like(y)
-        _lib.check(self.lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(red), P,
+        _lib.check(self.lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(asc),
+                                            _p(ash), _p(red), P,
                                             _p(grads[c.g_off:c.g_off + Cc]), _p(grads[c.b_off:c.b_off + Cc]),
                                             _p(dy), _p(dres), 1 if dres_acc else 0, n_pix, Cc, st),
                    "dt_bn_bwd_apply")
         return dy
 
-    def _wgrad(self, c: ConvSpec, grads, src0, src1, mode0, B, Hin, Win, dy):
+    def _wgrad(self, c: ConvSpec, grads, src0, src1, mode0, B, Hin, Win, dy, in_ss=None):
         Ho, Wo = dy.shape[1], dy.shape[2]
         C0 = src0.shape[-1]
         C1 = 0 if src1 is None else src1.shape[-1]
@@ -253,6 +273,7 @@ class UNetEngine:
         ws = self._buf("wgrad_ws", nbytes // 4, device=dy.device)
         _lib.check(self.lib.dt_conv2d_wgrad(C.byref(desc), _p(src0), _p(src1), _p(dy),
                                             _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
+                                            _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                             _stream()), "dt_conv2d_wgrad")
 
     def _dgrad(self, c: ConvSpec, params, dy, B, Hin, Win, out0, out1=None, split=0, acc=False):
@@ -305,15 +326,16 @@ class UNetEngine:
             blk = sp.decoder[i]
             d = S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
-            # conv2 + BN + ReLU
-            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"])
-            self._wgrad(blk.conv2, grads, d["z1"], None, 0, B, Hh, Ww, dy2)
-            dz1 = torch.empty_like(d["z1"])
+            # conv2 + BN + ReLU (activation stored only for the last block)
+            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"], virtual_act=d["z2"] is None)
+            self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+            dz1 = torch.empty_like(d["y1"])
             self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
             del dy2
-            dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, d["z1"], d["y1"])
+            dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, d["y1"], virtual_act=True)
             del dz1
-            self._wgrad(blk.conv1, grads, d["x"], d["skip"], 1, B, Hh, Ww, dy1)
+            x_ss = self._ss(sp.decoder[i - 1].conv2, bnws) if d["x_virtual"] else None
+            self._wgrad(blk.conv1, grads, d["x"], d["skip"], 1, B, Hh, Ww, dy1, in_ss=x_ss)
             cx = blk.in_ch
             dup = torch.empty((B, Hh, Ww, cx), dtype=torch.float32, device=dev)
             if d["skip"] is not None:
@@ -354,11 +376,11 @@ class UNetEngine:
                     dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, r["out"], r["y2"], dres=gd)
                     dyd = self._bn_bwd(blk.down, params, grads, bnws, gd, None, r["yd"])
                     del gd
-                self._wgrad(blk.conv2, grads, r["z1"], None, 0, B, Hh, Ww, dy2)
-                dz1 = torch.empty_like(r["z1"])
+                self._wgrad(blk.conv2, grads, r["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+                dz1 = torch.empty_like(r["y1"])
                 self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
                 del dy2
-                dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, r["z1"], r["y1"])
+                dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, r["y1"], virtual_act=True)
                 del dz1
                 self._wgrad(blk.conv1, grads, r["x"], None, 0, B, Hin, Win, dy1)
                 self._dgrad(blk.conv1, params, dy1, B, Hin, Win, gin, acc=gin_has)

@@ -35,7 +35,7 @@ def conv_desc(B, Hin, Win, C0, C1, mode0, Cout, k, stride, pad, split=0, acc=0):
 
 
 def conv2d(src0, w_hwio, k, stride, pad, src1=None, mode0=0, split=0, out0=None, out1=None, accumulate=False,
-           want_stats=False):
+           want_stats=False, in_scale=None, in_shift=None):
     """NHWC conv through dt_conv2d.  Returns (out0, out1, stats[2,P,Cout] or None)."""
     _gpu(src0, src1, w_hwio)
     lib = _lib.load()
@@ -60,7 +60,7 @@ def conv2d(src0, w_hwio, k, stride, pad, src1=None, mode0=0, split=0, out0=None,
             raise RuntimeError(lib.dt_last_error().decode())
         stats = torch.empty(lib.dt_bn_stats_floats(P, Cout), dtype=torch.float32, device=dev)
     _lib.check(lib.dt_conv2d(C.byref(d), _p(src0), _p(src1), _p(w_hwio.contiguous()), _p(out0), _p(out1), _p(stats),
-                             _st()), "dt_conv2d")
+                             _p(in_scale), _p(in_shift), _st()), "dt_conv2d")
     if stats is not None:
         stats = stats[:2 * P * Cout].view(2, P, Cout)
     return out0, out1, stats
@@ -75,7 +75,7 @@ def weight_flip_transpose(w_hwio):
     return wd
 
 
-def conv2d_wgrad(src0, dy, k, stride, pad, src1=None, mode0=0):
+def conv2d_wgrad(src0, dy, k, stride, pad, src1=None, mode0=0, in_scale=None, in_shift=None):
     _gpu(src0, src1, dy)
     lib = _lib.load()
     B = src0.shape[0]
@@ -90,8 +90,8 @@ def conv2d_wgrad(src0, dy, k, stride, pad, src1=None, mode0=0):
         raise RuntimeError(lib.dt_last_error().decode())
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
     dw = torch.empty((k, k, C0 + C1, Cout), dtype=torch.float32, device=dy.device)
-    _lib.check(lib.dt_conv2d_wgrad(C.byref(d), _p(src0), _p(src1), _p(dy.contiguous()), _p(dw), _p(ws), nbytes, _st()),
-               "dt_conv2d_wgrad")
+    _lib.check(lib.dt_conv2d_wgrad(C.byref(d), _p(src0), _p(src1), _p(dy.contiguous()), _p(dw), _p(ws), nbytes,
+                                   _p(in_scale), _p(in_shift), _st()), "dt_conv2d_wgrad")
     return dw
 
 
@@ -118,21 +118,22 @@ def bn_act(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
     return out
 
 
-def bn_backward(dout, out_act, y, mean, invstd, gamma, want_dres=False):
+def bn_backward(dout, out_act, y, mean, invstd, gamma, want_dres=False, act_scale=None, act_shift=None):
     _gpu(dout, y)
     lib = _lib.load()
     Cc = y.shape[-1]
     n_pix = y.numel() // Cc
     P = lib.dt_bn_bwd_rows(n_pix, Cc)
     red = torch.empty(lib.dt_bn_bwd_red_floats(n_pix, Cc), dtype=torch.float32, device=y.device)
-    _lib.check(lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(red), n_pix, Cc, _st()),
-               "dt_bn_bwd_reduce")
+    _lib.check(lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(act_scale), _p(act_shift),
+                                    _p(red), n_pix, Cc, _st()), "dt_bn_bwd_reduce")
     dgamma = torch.empty(Cc, dtype=torch.float32, device=y.device)
     dbeta = torch.empty_like(dgamma)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
-    _lib.check(lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(red), P,
-                                   _p(dgamma), _p(dbeta), _p(dy), _p(dres), 0, n_pix, Cc, _st()), "dt_bn_bwd_apply")
+    _lib.check(lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(act_scale),
+                                   _p(act_shift), _p(red), P, _p(dgamma), _p(dbeta), _p(dy), _p(dres), 0, n_pix, Cc,
+                                   _st()), "dt_bn_bwd_apply")
     return dy, dgamma, dbeta, dres
 
 

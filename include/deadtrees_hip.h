@@ -65,7 +65,10 @@ int dt_conv2d_stat_rows(const dt_conv_desc* d);
 /* y = conv(x, w) — replaces ATen conv2d reached from smp encoder/decoder (segmodel.py:214).
  * stats may be NULL.  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 fma chains. */
 int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const float* w_hwio,
-              float* out0, float* out1, float* stats, void* stream);
+              float* out0, float* out1, float* stats, const float* in_scale, const float* in_shift, void* stream);
+/* in_scale/in_shift (both NULL or both [C0]): source 0 is read as relu(src0*in_scale[c]+in_shift[c]) while it is
+ * staged into LDS — the BatchNorm-apply + ReLU of the producing layer fused into its consumer, so that activation
+ * never exists in HBM (zero padding stays zero).  Same pair on dt_conv2d_wgrad. */
 
 /* tile configuration dt_conv2d selects for d (kernel conv_fwd_kernel<ksize,stride,tw,tn,ck>): used to
  * attribute profiler rows and roofline numbers to launches. */
@@ -79,7 +82,8 @@ int dt_weight_flip_transpose(const float* w_hwio, float* wd, int ksize, int Cin,
  * in a fixed order -> run-to-run deterministic). */
 size_t dt_conv2d_wgrad_workspace(const dt_conv_desc* d);
 int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy,
-                    float* dw_hwio, float* workspace, size_t workspace_bytes, void* stream);
+                    float* dw_hwio, float* workspace, size_t workspace_bytes, const float* in_scale,
+                    const float* in_shift, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm / ReLU / residual (K2,K3,K8,K21) */
 /* stats[2][P][C] -> batch mean / biased var over `count` elements; writes mean, invstd, and the fused
@@ -103,13 +107,16 @@ int dt_bn_act(const float* y, const float* scale, const float* shift, const floa
  * -> red[2][P][C] with P = dt_bn_bwd_rows(n_pix); `red` holds dt_bn_bwd_red_floats(n_pix,C) floats. */
 int dt_bn_bwd_rows(int64_t n_pix, int C);
 int64_t dt_bn_bwd_red_floats(int64_t n_pix, int C);  /* size of `red` in floats (rows + reduction scratch) */
+/* ReLU mask of g: from out_act when given, else recomputed as (y*act_scale+act_shift > 0) when act_scale is
+ * given (virtual activation), else none (BatchNorm without ReLU: the downsample branch). */
 int dt_bn_bwd_reduce(const float* dout, const float* out_act, const float* y, const float* mean,
-                     const float* invstd, float* red, int64_t n_pix, int C, void* stream);
+                     const float* invstd, const float* act_scale, const float* act_shift, float* red,
+                     int64_t n_pix, int C, void* stream);
 /* pass 2: reduces red -> dgamma, dbeta (fp64, fixed order) and writes
  * dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));  if dres != NULL also dres (+)= g. */
 int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
-                    const float* invstd, const float* gamma, float* red, int P,
-                    float* dgamma, float* dbeta, float* dy, float* dres, int dres_accumulate,
+                    const float* invstd, const float* gamma, const float* act_scale, const float* act_shift,
+                    float* red, int P, float* dgamma, float* dbeta, float* dy, float* dres, int dres_accumulate,
                     int64_t n_pix, int C, void* stream);
 
 /* ------------------------------------------------------------------ pooling / resampling (K4,K9 bwd) */

@@ -118,6 +118,46 @@ def test_conv_n16_with_virtual_upsample():
     np.testing.assert_allclose(stats[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-5)
 
 
+@pytest.mark.parametrize("Cin,Cout,up", [(64, 64, False), (32, 16, True), (128, 32, True), (16, 16, False)])
+def test_conv_fused_input_bn_relu(Cin, Cout, up):
+    """virtual activation: conv / wgrad read relu(src*scale+shift) while staging; zero padding must stay zero"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Cin + Cout)
+    B, h, w_ = 2, 20, 36
+    yraw = torch.randn((B, Cin, h, w_), generator=g)
+    sc = 1 + 0.3 * torch.randn(Cin, generator=g)
+    sh = 0.2 * torch.randn(Cin, generator=g) + 0.5      # shift != 0: a transformed padding pixel would show up
+    wt = (torch.randn((Cout, Cin, 3, 3), generator=g) * 0.07).double().requires_grad_(True)
+    z = F.relu(yraw.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None])
+    zin = F.interpolate(z, scale_factor=2, mode="nearest") if up else z
+    ref = F.conv2d(zin, wt, padding=1)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    y, _, _ = ops.conv2d(nhwc(yraw), hwio(wt.detach()), 3, 1, 1, mode0=1 if up else 0, in_scale=sc.to(DEV),
+                         in_shift=sh.to(DEV))
+    assert rel_err(to_nchw(y), ref.detach()) < 3e-6
+    dw = ops.conv2d_wgrad(nhwc(yraw), nhwc(dy), 3, 1, 1, mode0=1 if up else 0, in_scale=sc.to(DEV), in_shift=sh.to(DEV))
+    assert rel_err(dw.cpu().permute(3, 2, 0, 1), wt.grad) < 3e-6
+
+
+def test_bn_backward_mask_from_raw_output():
+    """BN backward with the ReLU mask recomputed from y (no stored activation) == with the stored activation"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    B, H, W, C = 2, 24, 40, 32
+    y = torch.randn((B, H, W, C), generator=g).to(DEV)
+    dout = torch.randn((B, H, W, C), generator=g).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    stats = torch.stack([y.sum(dim=(0, 1, 2)), (y * y).sum(dim=(0, 1, 2))]).reshape(2, 1, C).contiguous()
+    mean, invstd, scale, shift = ops.bn_finalize(stats, B * H * W, gamma, beta)
+    z = ops.bn_act(y, scale, shift, relu=True)
+    a = ops.bn_backward(dout, z, y, mean, invstd, gamma)
+    b = ops.bn_backward(dout, None, y, mean, invstd, gamma, act_scale=scale, act_shift=shift)
+    for u, v in zip(a[:3], b[:3]):
+        assert torch.equal(u, v)
+
+
 def test_conv_dgrad_stride1():
     ops = _ops()
     g = torch.Generator().manual_seed(12)
