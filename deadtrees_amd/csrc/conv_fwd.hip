@@ -160,6 +160,34 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ lds_in, cons
   }
 }
 
+// explicitly software-pipelined variant: the fragments of step i+1 are loaded before the MFMAs of step i
+template <int KS, int TN, int CK, int PLANE, int HALO_W>
+__device__ __forceinline__ void mma_chunk_v1(const float* __restrict__ lds_in, const float* __restrict__ lds_w,
+                                             const int (&abase)[2], int bbase, f32x16 (&acc)[2][TN / 32]) {
+  constexpr int NT = TN / 32;
+  constexpr int STEPS = KS * KS * (CK / 2);
+  float av[2][2], bv[2][NT];
+  auto load = [&](int step, int buf) {
+    const int tap = step / (CK / 2), kk = step % (CK / 2);
+    const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) av[buf][mt] = lds_in[abase[mt] + 2 * kk * PLANE + kh * HALO_W + kw];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[buf][j] = lds_w[bbase + (tap * CK + 2 * kk) * TN + 32 * j];
+  };
+  load(0, 0);
+#pragma unroll
+  for (int step = 0; step < STEPS; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < STEPS) load(step + 1, cur ^ 1);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mt], bv[cur][j], acc[mt][j], 0, 0, 0);
+  }
+}
+
 // zero-insertion variant: per row-tile tap mask (wave-uniform), B fragments re-read per tile
 template <int KS, int TN, int CK, int PLANE, int HALO_W>
 __device__ __forceinline__ void mma_chunk_zi(const float* __restrict__ lds_in, const float* __restrict__ lds_w,
@@ -401,7 +429,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
       if constexpr (ZI)
         mma_chunk_zi<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc, wave, a.pad);
       else
-        mma_chunk<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
+        mma_chunk_v1<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc);
     }
   }
 
