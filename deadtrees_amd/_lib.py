@@ -32,6 +32,7 @@ SIGNATURES = {
     "dt_conv2d_stat_rows": (C.c_int, [_P]),
     "dt_conv2d": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_config": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dt_conv2d_uses_zi": (C.c_int, [_P]),
     "dt_weight_flip_transpose": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),
     "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),

@@ -656,6 +656,13 @@ extern "C" int dt_weight_flip_transpose(const float* w, float* wd, int ksize, in
 }
 
 // which kernel instantiation dt_conv2d launches for a descriptor (profiling / roofline attribution)
+// 1 when dt_conv2d runs the parity-class (zero-insertion) tiles for this descriptor
+extern "C" int dt_conv2d_uses_zi(const dt_conv_desc* d) {
+  if (validate(d) != DT_OK) return 0;
+  ConvCfg c = pick_cfg(d);
+  return d->mode0 == 2 && d->stride == 1 && c.tw == 32 && d->C0 > 32 && (d->ksize == 3 || d->ksize == 1);
+}
+
 extern "C" int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck) {
   int rc = validate(d);
   if (rc != DT_OK) return rc;

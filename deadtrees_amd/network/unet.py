@@ -65,10 +65,15 @@ class UNetEngine:
     def _desc(self, B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split=0, acc=0):
         return _lib.ConvDesc(B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split, acc)
 
-    def _conv_kernel_name(self, desc) -> str:
+    def _conv_kernel_name(self, desc, transformed: bool = False) -> str:
+        """name of the kernel instantiation dt_conv2d launches, spelled like rocprofv3 prints it"""
         tw, tn, ck = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self.lib.dt_conv2d_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck)), "dt_conv2d_config")
-        return f"conv_fwd_kernel<{desc.ksize},{desc.stride},{tw.value},{tn.value},{ck.value}>"
+        if tn.value == 16:
+            return "conv_fwd_n16_kernel"
+        zi = "true" if self.lib.dt_conv2d_uses_zi(C.byref(desc)) else "false"
+        tf = "true" if transformed else "false"
+        return f"conv_fwd_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, {zi}, {tf}>"
 
     def _conv(self, desc, src0, src1, w, out0, out1=None, stats=None, in_ss=None):
         prof = self.profile
@@ -89,7 +94,7 @@ class UNetEngine:
             nbytes = 4.0 * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
                                      desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
                 4.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
-            prof.append((self._conv_kernel_name(desc), flops, e0, e1, nbytes))
+            prof.append((self._conv_kernel_name(desc, in_ss is not None), flops, e0, e1, nbytes))
 
     # ------------------------------------------------------------------ forward units
     def _ss(self, c: ConvSpec, bnws):

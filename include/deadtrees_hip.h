@@ -73,6 +73,7 @@ int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const
 /* tile configuration dt_conv2d selects for d (kernel conv_fwd_kernel<ksize,stride,tw,tn,ck>): used to
  * attribute profiler rows and roofline numbers to launches. */
 int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck);
+int dt_conv2d_uses_zi(const dt_conv_desc* d);  /* 1: parity-class tiles of the transposed (stride-2) data gradient */
 
 /* wd[kh'][kw'][co][ci] = w[K-1-kh'][K-1-kw'][ci][co]: weights of the data-gradient convolution. */
 int dt_weight_flip_transpose(const float* w_hwio, float* wd, int ksize, int Cin, int Cout, void* stream);
