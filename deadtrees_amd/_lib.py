@@ -59,6 +59,7 @@ SIGNATURES = {
     "dt_seg_loss_acc_doubles": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_confusion_matrix": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, I64, c_f, c_f, c_f]),
     "dt_sumsq_rows": (C.c_int, [I64]),
     "dt_sumsq": (C.c_int, [c_f, I64, c_f, c_f]),
     "dt_clip_coef": (C.c_int, [c_f, C.c_int, F32, F32, c_f, c_f, c_f]),

@@ -441,3 +441,45 @@ extern "C" int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
+
+// ------------------------------------------------------------------ confusion matrices (eval reductions)
+// Replaces torchmetrics.functional.confusion_matrix over the concatenated int64 masks of a whole epoch
+// (reference deadtrees/network/segmodel.py:291-309, 337-365: 4 passes over N*H*W int64 x3 kept in memory):
+// per batch, counts[0][t][p] += 1 for every pixel and counts[1][t][p] += 1 where lu == 1 (forest mask).
+// Integer atomics: exact and order independent.
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ pred, const uint8_t* __restrict__ pred8,
+                                                        const int64_t* __restrict__ target,
+                                                        const int64_t* __restrict__ lu, int K, int64_t n,
+                                                        unsigned long long* __restrict__ counts, int32_t* __restrict__ err) {
+  __shared__ unsigned int hist[2 * HEAD_MAXK * HEAD_MAXK];
+  for (int i = threadIdx.x; i < 2 * K * K; i += 256) hist[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t p = pred ? pred[i] : (int64_t)pred8[i];
+    const int64_t t = target[i];
+    if (p < 0 || p >= K || t < 0 || t >= K) {
+      err[0] = 1;
+      continue;
+    }
+    atomicAdd(&hist[t * K + p], 1u);
+    if (lu && lu[i] == 1) atomicAdd(&hist[K * K + t * K + p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * K * K; i += 256)
+    if (hist[i]) atomicAdd(&counts[i], (unsigned long long)hist[i]);
+}
+
+extern "C" int dt_confusion_matrix(const int64_t* pred_i64, const uint8_t* pred_u8, const int64_t* target,
+                                   const int64_t* lu, int K, int64_t n, int64_t* counts, int32_t* err_flag,
+                                   void* stream) {
+  DT_REQUIRE((pred_i64 != nullptr) != (pred_u8 != nullptr), "confusion: exactly one of pred_i64 / pred_u8");
+  DT_REQUIRE(target && counts && err_flag && n > 0 && K >= 2 && K <= HEAD_MAXK, "confusion: bad args");
+  int64_t g = (n + 256 * 16 - 1) / (256 * 16);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pred_i64, pred_u8, target,
+                     lu, K, n, (unsigned long long*)counts, err_flag);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

@@ -143,6 +143,9 @@ class SemSegment(_Base):
 
         self.stats = {"train": Counter(), "val": Counter(), "test": Counter()}
         self.label_error = None  # device flag: labels outside [0,K) seen (class2one_hot's assert, lazily)
+        # device-side confusion counts [2,K,K] per stage (all pixels / lu == 1), instead of concatenating every
+        # int64 mask of the epoch (reference validation_epoch_end / test_epoch_end, segmodel.py:291-407)
+        self._cm = {}
 
     # ------------------------------------------------------------------ reference helpers
     @property
@@ -186,7 +189,9 @@ class SemSegment(_Base):
         loss, parts = self.calculate_loss(logits, mask, stage="val", distmap=distmap)
         self.log_metrics(parts, stage="val")
         self.stats["val"].update([x["file"] for x in stats])
-        return {"val_loss": loss, "target": mask, "prediction": logits.argmax(dim=1), "lu": lu}
+        pred = logits.argmax(dim=1)
+        self._accumulate_cm("val", pred, mask, lu)
+        return {"val_loss": loss, "target": mask, "prediction": pred, "lu": lu}
 
     def test_step(self, batch: Tuple[Tensor], batch_idx) -> Dict[str, Any]:
         img, mask, _, lu, stats = batch
@@ -195,7 +200,32 @@ class SemSegment(_Base):
         self.label_error = err
         self.log_metrics(parts, stage="test")
         self.stats["test"].update([x["file"] for x in stats])
-        return {"target": mask, "prediction": logits.argmax(dim=1), "lu": lu}
+        pred = logits.argmax(dim=1)
+        self._accumulate_cm("test", pred, mask, lu)
+        return {"target": mask, "prediction": pred, "lu": lu}
+
+    def _accumulate_cm(self, stage, pred, mask, lu):
+        from ..ops import confusion_matrix
+        self._cm[stage], _ = confusion_matrix(pred, mask, lu, K=len(self.classes), counts=self._cm.get(stage))
+
+    def confusion_matrices(self, stage: str):
+        """{"cm_px", "cm_norm", "cm_px_masked", "cm_norm_masked"} as the reference's *_epoch_end builds them
+        (normalize="true": rows sum to 1); resets the accumulator."""
+        cm = self._cm.pop(stage, None)
+        if cm is None:
+            return {}
+        cm = cm.cpu().double()
+        out = {}
+        for name, m in (("", cm[0]), ("_masked", cm[1])):
+            out[f"cm_px{name}"] = m.to(torch.int64)
+            out[f"cm_norm{name}"] = m / m.sum(dim=1, keepdim=True).clamp_min(1.0)
+        return out
+
+    def validation_epoch_end(self, outputs=None):
+        return self.confusion_matrices("val")
+
+    def test_epoch_end(self, outputs=None):
+        return self.confusion_matrices("test")
 
     def configure_optimizers(self):
         opt = torch.optim.Adam(self.parameters(), lr=self.hparams["training"]["learning_rate"])

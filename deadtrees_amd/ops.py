@@ -223,6 +223,23 @@ def head_bwd(x, w_ohwi, dlogits):
     return dx, dw, db
 
 
+def confusion_matrix(pred, target, lu=None, K=2, counts=None):
+    """counts int64 [2,K,K] (+=): [0] all pixels, [1] pixels with lu == 1; rows target, cols prediction."""
+    _gpu(pred, target, lu)
+    if counts is None:
+        counts = torch.zeros((2, K, K), dtype=torch.int64, device=pred.device)
+    err = torch.zeros(1, dtype=torch.int32, device=pred.device)
+    pred = pred.contiguous()
+    p64 = pred if pred.dtype == torch.int64 else None
+    p8 = pred if pred.dtype == torch.uint8 else None
+    if p64 is None and p8 is None:
+        raise RuntimeError("confusion_matrix: prediction must be int64 or uint8")
+    _lib.check(_lib.load().dt_confusion_matrix(_p(p64), _p(p8), _p(target.contiguous()),
+                                               _p(lu.contiguous()) if lu is not None else None, K, pred.numel(),
+                                               _p(counts), _p(err), _st()), "dt_confusion_matrix")
+    return counts, err
+
+
 class FlatAdam:
     """clip_grad_norm_(max_norm) + torch.optim.Adam on one flat buffer, two fused HIP passes
     (reference: configs/trainer/default.yaml:18 + segmodel.py:420-425)."""

@@ -168,6 +168,12 @@ int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dis
                     const float* wfocal, const float* wbound, const float* gscale, float* dlogits,
                     int B, int K, int H, int W, void* stream);
 
+/* K x K confusion counts accumulated on the device (eval reductions, segmodel.py:291-309,337-365):
+ * counts int64 [2][K][K] (+=): plane 0 all pixels, plane 1 pixels with lu == 1 (lu may be NULL);
+ * rows = target, columns = prediction.  Give the prediction as int64 OR uint8 (the other pointer NULL). */
+int dt_confusion_matrix(const int64_t* pred_i64, const uint8_t* pred_u8, const int64_t* target, const int64_t* lu,
+                        int K, int64_t n, int64_t* counts, int32_t* err_flag, void* stream);
+
 /* ------------------------------------------------------------------ optimiser (K22) */
 /* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
 int dt_sumsq_rows(int64_t n);

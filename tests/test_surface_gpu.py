@@ -80,6 +80,28 @@ def test_semsegment_steps():
         out = model.test_step(next(iter(dm.test_dataloader())), 0)
         assert set(out) == {"target", "prediction", "lu"}
     assert int(model.label_error) == 0
+    cms = model.test_epoch_end()
+    assert set(cms) == {"cm_px", "cm_norm", "cm_px_masked", "cm_norm_masked"}
+    assert int(cms["cm_px"].sum()) == 2 * 64 * 64
+    assert set(model.validation_epoch_end()) == set(cms)
+
+
+def test_confusion_matrix_kernel():
+    from deadtrees_amd import ops
+    g = torch.Generator().manual_seed(2)
+    K = 3
+    pred = torch.randint(0, K, (4, 96, 96), generator=g)
+    tgt = torch.randint(0, K, (4, 96, 96), generator=g)
+    lu = torch.randint(0, 3, (4, 96, 96), generator=g)
+    counts, err = ops.confusion_matrix(pred.to(DEV), tgt.to(DEV), lu.to(DEV), K=K)
+    counts, err = ops.confusion_matrix(pred.to(torch.uint8).to(DEV), tgt.to(DEV), lu.to(DEV), K=K, counts=counts)
+    want = torch.zeros((K, K), dtype=torch.int64)
+    wantm = torch.zeros((K, K), dtype=torch.int64)
+    idx = (tgt * K + pred).flatten()
+    want += torch.bincount(idx, minlength=K * K).view(K, K)
+    wantm += torch.bincount(idx[lu.flatten() == 1], minlength=K * K).view(K, K)
+    assert int(err) == 0
+    assert torch.equal(counts[0].cpu(), 2 * want) and torch.equal(counts[1].cpu(), 2 * wantm)
 
 
 def test_inference_checkpoint_fused_argmax_and_tiles(tmp_path):
