@@ -84,3 +84,25 @@ class HipTrainer:
         m.flat_params.grad = None
         self.last = {"loss": loss.detach(), "parts": parts, "grad_norm": norm, "label_error": err, "skipped": skip}
         return loss.detach()
+
+
+def fit(trainer: HipTrainer, loader, epochs: int, base_lr: float = 3e-4, t_max: int = 10, to_device=None,
+        on_epoch_end=None):
+    """Minimal stand-in for ``Trainer.fit`` on the hot path (reference deadtrees/train.py:113): per-batch
+    ``HipTrainer.step`` and the per-epoch ``CosineAnnealingLR(T_max)`` of segmodel.py:426-428."""
+    from .network.segmodel import cosine_lr, create_combined_batch
+    history = []
+    for epoch in range(epochs):
+        trainer.opt.lr = cosine_lr(base_lr, epoch, t_max)
+        losses = []
+        for batch in loader:
+            img, mask, distmap, _, _ = create_combined_batch(batch) if isinstance(batch, dict) else batch
+            if to_device:
+                img, mask, distmap = img.to(to_device), mask.to(to_device), distmap.to(to_device)
+            alpha = min((epoch + 1) * 0.01, 0.99)
+            losses.append(trainer.step(img, mask, distmap, alpha=alpha))
+        mean = float(torch.stack(losses).mean()) if losses else float("nan")
+        history.append({"epoch": epoch, "lr": trainer.opt.lr, "train/total_loss": mean})
+        if on_epoch_end:
+            on_epoch_end(history[-1])
+    return history

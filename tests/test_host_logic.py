@@ -163,3 +163,13 @@ def test_transforms_and_synthetic_data():
     img_t, mask, dist, lu, stats = batch["main"]
     assert img_t.shape == (2, 3, 64, 64) and dist.shape == (2, 2, 64, 64) and len(stats) == 2
     assert isinstance(next(iter(dm.test_dataloader())), tuple)
+
+
+def test_distmap_matches_reference_golden(golden_dir):
+    """product-side one_hot2dist (loader step) against the maps the imported reference produced"""
+    import glob
+    from deadtrees_amd.data.distmap import distmaps_for_batch
+    for path in sorted(glob.glob(os.path.join(golden_dir, "losses_*.npz"))):
+        z = np.load(path)
+        got = distmaps_for_batch(torch.from_numpy(z["mask"]), z["logits"].shape[1])
+        np.testing.assert_array_equal(got.numpy(), z["distmap"])

@@ -137,3 +137,28 @@ def test_inference_checkpoint_fused_argmax_and_tiles(tmp_path):
     from deadtrees_amd.deployment.tiler import unmake_blocks_vectorized
     want_merged = unmake_blocks_vectorized([am.numpy().astype(np.uint8)], 256, 512, 512)
     assert float((merged != want_merged).mean()) < 1e-4                  # fp32 normalise on device vs host
+
+
+def test_fit_loop_with_cosine_schedule_and_boundary_loss():
+    from deadtrees_amd.data.deadtreedata import DeadtreesDataModule
+    from deadtrees_amd.data.distmap import distmaps_for_batch
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.trainer import HipTrainer, fit
+
+    class WithDist:
+        def __init__(self, loader):
+            self.loader = loader
+
+        def __iter__(self):
+            for b in self.loader:
+                img, mask, _, lu, stats = b["main"]
+                yield {"main": (img, mask, distmaps_for_batch(mask, 2), lu, stats)}
+
+    dm = DeadtreesDataModule(train_dataloader_conf={"batch_size": 2}, synthetic_batches=2, tile_size=64)
+    dm.setup(in_channels=3, classes=2)
+    m = UNetHIP().to(DEV)
+    tr = HipTrainer(m, losses=("GDICE", "BOUNDARY-RAMPED", "FOCAL"))
+    hist = fit(tr, WithDist(dm.train_dataloader()), epochs=3, base_lr=3e-4, t_max=10, to_device=DEV)
+    assert [round(h["lr"] / 3e-4, 4) for h in hist] == [1.0, 0.9755, 0.9045]
+    assert all(np.isfinite(h["train/total_loss"]) for h in hist)
+    assert hist[-1]["train/total_loss"] < hist[0]["train/total_loss"]      # it learns on the repeated batches
