@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="inference mode only")
     ap.add_argument("--mode", choices=["train", "infer"], default="train",
                     help="train = BASELINE configs[1] (the headline metric); infer = tiled-inference forward "
                          "(uint8 tiles -> uint8 class maps, BASELINE configs[4] per-GPU leg)")
@@ -187,7 +188,7 @@ def infer_bench(args, model, dev, world, rank, distributed):
 
     def step():
         x = ops.normalize_u8(u8, MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
-        return model.predict_classes(x, dtype="uint8")
+        return model.predict_classes(x, dtype="uint8", precision=args.precision)
 
     for _ in range(args.warmup):
         step()
@@ -210,7 +211,8 @@ def infer_bench(args, model, dev, world, rank, distributed):
     fwd_flop = 62.59e9 * (S / 512.0) ** 2
     res = {"metric": f"{S}x{S} RGB tiles/sec (inference fwd + argmax)", "value": round(tiles_s, 1), "unit": "tiles/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if args.precision == "fp32" else "bf16 (fp32 accumulate)", "data": "synthetic",
            "config": {"workload": f"tiled inference leg: uint8 {S}x{S}x4 sub-tiles, batch {B}/GPU, fused normalise + "
                                   "forward + uint8 argmax", "global_batch": B * world, "parallelism": f"dp{world}"},
            "km2_per_hour": round(tiles_s * km2_per_tile * 3600.0, 1),

@@ -243,6 +243,108 @@ class UNetEngine:
             self.saved = sv
         return logits, (am64 if am64 is not None else am8)
 
+    # ------------------------------------------------------------------ bf16 inference leg
+    def _bf16_weights(self, params: torch.Tensor):
+        """bf16 [tap][Cout][Cin] copies of every conv weight except stem and head, repacked when the flat
+        parameter buffer changed (tracked by its version counter)."""
+        key = (params.data_ptr(), params._version)
+        if self._ws.get("bf16_key") == key:
+            return self._ws["bf16_w"]
+        buf = torch.empty(self.spec.n_params, dtype=torch.bfloat16, device=params.device)
+        for c in self.spec.convs:
+            if c is self.spec.stem or c.bn_key is None:
+                continue
+            _lib.check(self.lib.dt_pack_weights_bf16(_p(params[c.w_off:c.w_off + c.w_size]),
+                                                     _p(buf[c.w_off:c.w_off + c.w_size]), c.k, c.cin, c.cout,
+                                                     _stream()), "dt_pack_weights_bf16")
+        self._ws["bf16_key"], self._ws["bf16_w"] = key, buf
+        return buf
+
+    def forward_bf16_eval(self, x_nchw: torch.Tensor, params: torch.Tensor, bnstate: torch.Tensor,
+                          want_argmax: Optional[str] = None):
+        """eval-mode forward with bf16 activations/weights and fp32 accumulation (stem and head stay fp32)."""
+        sp, lib = self.spec, self.lib
+        if x_nchw.dim() != 4 or x_nchw.shape[1] != sp.in_channels:
+            raise RuntimeError(f"expected input [B,{sp.in_channels},H,W], got {tuple(x_nchw.shape)}")
+        B, Cin, H, W = x_nchw.shape
+        if H % 32 or W % 32:
+            raise RuntimeError(f"H and W must be divisible by 32 (encoder depth 5), got {H}x{W}")
+        dev = x_nchw.device
+        st = _stream()
+        wb = self._bf16_weights(params)
+        bnws = self._buf("bnws", 4 * sp.n_bn_channels, device=dev)
+        bf = torch.bfloat16
+
+        def affine(c):
+            ss = self._ss(c, bnws)
+            _lib.check(lib.dt_bn_eval_affine(_p(params[c.g_off:c.g_off + c.cout]), _p(params[c.b_off:c.b_off + c.cout]),
+                                             _p(bnstate[2 * c.bn_off:2 * c.bn_off + c.cout]),
+                                             _p(bnstate[2 * c.bn_off + c.cout:2 * c.bn_off + 2 * c.cout]), BN_EPS,
+                                             c.cout, _p(ss[0]), _p(ss[1]), st), "dt_bn_eval_affine")
+            return ss
+
+        def conv(c, src0, src1, mode0, Hin, Win, in_ss=None):
+            Ho = (Hin + 2 * c.pad - c.k) // c.stride + 1
+            Wo = (Win + 2 * c.pad - c.k) // c.stride + 1
+            C0 = src0.shape[-1]
+            C1 = 0 if src1 is None else src1.shape[-1]
+            desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
+            y = torch.empty((B, Ho, Wo, c.cout), dtype=bf, device=dev)
+            _lib.check(lib.dt_conv2d_bf16(C.byref(desc), _p(src0), _p(src1), _p(wb[c.w_off:c.w_off + c.w_size]), _p(y),
+                                          _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None, st),
+                       "dt_conv2d_bf16")
+            return y, Ho, Wo, affine(c)
+
+        def bn_act(y, ss, res=None, res_ss=None, y_f32=False):
+            Bq, Hq, Wq, Cq = y.shape
+            z = torch.empty((Bq, Hq, Wq, Cq), dtype=bf, device=dev)
+            _lib.check(lib.dt_bn_act_bf16(_p(y), 1 if y_f32 else 0, _p(ss[0]), _p(ss[1]), _p(res),
+                                          _p(res_ss[0]) if res_ss else None, _p(res_ss[1]) if res_ss else None, _p(z),
+                                          Bq * Hq * Wq, Cq, 1, st), "dt_bn_act_bf16")
+            return z
+
+        x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw.contiguous()), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
+        # stem in fp32 (K = 147, output-write bound), rounded to bf16 by its BN-apply
+        y, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, False)
+        f1 = bn_act(y, ss, y_f32=True)
+        hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+        pool = torch.empty((B, hp, wp, 64), dtype=bf, device=dev)
+        _lib.check(lib.dt_maxpool3x3s2_bf16(_p(f1), _p(pool), B, h, w_, 64, st), "dt_maxpool3x3s2_bf16")
+        feats = [f1]
+        cur, ch, cw = pool, hp, wp
+        for blocks in sp.layers:
+            for blk in blocks:
+                y1, h1, w1, ss1 = conv(blk.conv1, cur, None, 0, ch, cw)
+                y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+                if blk.down is not None:
+                    yd, _, _, ssd = conv(blk.down, cur, None, 0, ch, cw)
+                    out = bn_act(y2, ss2, res=yd, res_ss=ssd)
+                else:
+                    out = bn_act(y2, ss2, res=cur)
+                cur, ch, cw = out, h2, w2
+            feats.append(cur)
+        d, dh, dw, d_ss = feats[4], ch, cw, None
+        skips = [feats[3], feats[2], feats[1], feats[0], None]
+        for i, blk in enumerate(sp.decoder):
+            y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw, in_ss=d_ss)
+            y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+            if i == len(sp.decoder) - 1:
+                d, d_ss = bn_act(y2, ss2), None
+            else:
+                d, d_ss = y2, ss2
+            dh, dw = h2, w2
+        hd = sp.head
+        K = hd.cout
+        d32 = torch.empty((B, dh, dw, hd.cin), dtype=torch.float32, device=dev)
+        _lib.check(lib.dt_bf16_to_f32(_p(d), _p(d32), d.numel(), st), "dt_bf16_to_f32")
+        logits = torch.empty((B, K, dh, dw), dtype=torch.float32, device=dev)
+        am64 = torch.empty((B, dh, dw), dtype=torch.int64, device=dev) if want_argmax == "int64" else None
+        am8 = torch.empty((B, dh, dw), dtype=torch.uint8, device=dev) if want_argmax == "uint8" else None
+        _lib.check(lib.dt_head_fwd(_p(d32), _p(params[hd.w_off:hd.w_off + hd.w_size]), _p(params[hd.b_off:hd.b_off + K]),
+                                   _p(logits), _p(am64), _p(am8), B, dh, dw, hd.cin, K, st), "dt_head_fwd")
+        return logits, (am64 if am64 is not None else am8)
+
     # ------------------------------------------------------------------ backward units
     def _bn_bwd(self, c: ConvSpec, params, grads, bnws, dout, out_act, y, dres=None, dres_acc=False,
                 virtual_act=False):
@@ -602,9 +704,16 @@ class UNetHIP(nn.Module):
         return logits
 
     @torch.no_grad()
-    def predict_classes(self, x: torch.Tensor, dtype: str = "int64") -> torch.Tensor:
-        """forward + argmax fused in the head kernel (deployment/inference.py:60-62), eval-mode BN."""
+    def predict_classes(self, x: torch.Tensor, dtype: str = "int64", precision: str = "fp32") -> torch.Tensor:
+        """forward + argmax fused in the head kernel (deployment/inference.py:60-62), eval-mode BN.
+        precision "bf16": bf16 activations/weights with fp32 accumulation (the AMP setting of the reference's
+        training protocol) — class maps agree with fp32 wherever the logit margin exceeds bf16 rounding."""
         self._require_gpu(x)
+        if precision == "bf16":
+            _, am = self.engine.forward_bf16_eval(x.float(), self.flat_params.detach(), self.bn_state, want_argmax=dtype)
+            return am
+        if precision != "fp32":
+            raise ValueError(f"precision {precision!r}: use 'fp32' or 'bf16'")
         was = self.training
         self.eval()
         try:
@@ -613,3 +722,10 @@ class UNetHIP(nn.Module):
         finally:
             self.train(was)
         return am
+
+    @torch.no_grad()
+    def forward_bf16(self, x: torch.Tensor) -> torch.Tensor:
+        """eval-mode logits (fp32 tensor) from the bf16 path"""
+        self._require_gpu(x)
+        logits, _ = self.engine.forward_bf16_eval(x.float(), self.flat_params.detach(), self.bn_state)
+        return logits

@@ -174,6 +174,19 @@ int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dis
 int dt_confusion_matrix(const int64_t* pred_i64, const uint8_t* pred_u8, const int64_t* target, const int64_t* lu,
                         int K, int64_t n, int64_t* counts, int32_t* err_flag, void* stream);
 
+/* ------------------------------------------------------------------ bf16 storage / fp32 accumulate (inference leg)
+ * BASELINE configs[2] precision: activations NHWC bf16, weights [tap][Cout][Cin] bf16 (dt_pack_weights_bf16),
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulators, one rounding at the store.  Same descriptor semantics as
+ * dt_conv2d (mode0 0/1, concat, fused input BatchNorm-apply + ReLU); no split/accumulate/statistics yet. */
+int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16, void* out,
+                   const float* in_scale, const float* in_shift, void* stream);
+int dt_pack_weights_bf16(const float* w_hwio, void* out_bf16, int ksize, int Cin, int Cout, void* stream);
+/* out(bf16) = act(y*scale+shift + res'), y fp32 (y_is_f32) or bf16, res bf16 (optional affine) */
+int dt_bn_act_bf16(const void* y, int y_is_f32, const float* scale, const float* shift, const void* res,
+                   const float* rscale, const float* rshift, void* out, int64_t n_pix, int C, int relu, void* stream);
+int dt_maxpool3x3s2_bf16(const void* x, void* out, int B, int H, int W, int C, void* stream);
+int dt_bf16_to_f32(const void* x, float* out, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------ optimiser (K22) */
 /* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
 int dt_sumsq_rows(int64_t n);

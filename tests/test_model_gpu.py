@@ -165,3 +165,31 @@ def test_fscore_matches_oracle_and_label_error_flag():
     bad[0, 0, 0] = 7
     _, _, err = seg_loss(logits.to(DEV), bad.to(DEV), None, ("GDICE",))
     assert int(err) == 1
+
+
+@pytest.mark.parametrize("B,H,W,C,K", [(2, 128, 128, 3, 2), (1, 256, 256, 4, 3)])
+def test_bf16_inference_leg_against_fp32(B, H, W, C, K):
+    """bf16 storage / fp32 accumulate forward vs the fp64 oracle and the fp32 HIP path.  Tolerance (bf16 has 8
+    significant bits and ~50 roundings sit between image and logits): relative L2 error of the logits <= 2e-2,
+    max error <= 5e-2 of max|logit|; class maps identical wherever the logit margin exceeds the max error."""
+    ref, m = _pair(C, K)
+    img, _ = _synth(B, H, W, C, K)
+    m.eval()
+    ref.eval()
+    with torch.no_grad():
+        want64 = ref.double()(img.double())
+        l32 = m(img.to(DEV)).cpu()
+        l16 = m.forward_bf16(img.to(DEV)).cpu()
+    scale = float(want64.abs().max())
+    err16 = float((l16.double() - want64).abs().max())
+    rel_l2 = float((l16.double() - want64).norm() / want64.norm())
+    print(f"bf16: rel L2 {rel_l2:.3e}, max err {err16 / scale:.3e} of max|logit|")
+    assert rel_l2 <= 2e-2, rel_l2
+    assert err16 <= 5e-2 * scale, (err16, scale)
+    assert float((l16 - l32).abs().max()) <= 5e-2 * scale
+    am16 = m.predict_classes(img.to(DEV), precision="bf16").cpu()
+    assert torch.equal(am16, l16.argmax(dim=1))
+    top2 = want64.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * err16
+    assert torch.equal(am16[safe], want64.argmax(dim=1)[safe])
+    assert float((am16 == want64.argmax(dim=1)).float().mean()) > 0.97
