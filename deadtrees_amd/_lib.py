@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first: it ships its own HIP runtime (libamdhip64) — the kernels of libdeadtrees_hip.so must launch through
+# THAT instance (the one that owns the device context, streams and allocations), so it has to be resident before
+# the library is dlopen-ed.  Loading ours first binds it to /opt/rocm's copy, which then sees no device.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdeadtrees_hip.so")
 
