@@ -65,7 +65,11 @@ SIGNATURES = {
     "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_confusion_matrix": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, I64, c_f, c_f, c_f]),
-    "dt_conv2d_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "dt_conv2d_bf16_stat_rows": (C.c_int, [_P]),
+    "dt_conv2d_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "dt_conv2d_wgrad_bf16_workspace": (SZ, [_P]),
+    "dt_conv2d_wgrad_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),
+    "dt_pack_dgrad_weights_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_pack_weights_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_bn_act_bf16": (C.c_int, [c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, C.c_int, c_f]),
     "dt_maxpool3x3s2_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

@@ -22,7 +22,9 @@ struct ConvBfArgs {
   const float* in_scale;
   const float* in_shift;
   __bf16* out;
-  int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, n_tiles, P;
+  __bf16* out1;     // channels >= cout_split (decoder concat data gradient)
+  float* stats;     // [2][P][Cout] BatchNorm partial sums from the fp32 accumulators, or null
+  int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, n_tiles, P, cout_split, accumulate;
 };
 
 #define BF_CK 32
@@ -93,7 +95,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
     const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
     const bool inb = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && pix < IN_ROWS;
     const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
-    pidx0[it] = inb ? (b * Hs0 + sy) * Ws0 + sx : -1;
+    bool ok0 = inb;
+    if (a.mode0 == 2) ok0 = ok0 && (((iy | ix) & 1) == 0);   // zero-insertion (transposed conv)
+    pidx0[it] = ok0 ? (b * Hs0 + sy) * Ws0 + sx : -1;
     pidx1[it] = inb ? (b * a.Hin + iy) * a.Win + ix : -1;
   }
   int woff[W_IT];
@@ -189,32 +193,87 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
     }
   }
   // epilogue: D col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*(lane>>5) (pixel)
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + 32 * j + r;
-    if (n >= a.Cout) continue;
+    __bf16* outp = a.out;
+    int ld = a.Cout, nn = n;
+    if (a.cout_split > 0) {
+      if (n0 >= a.cout_split) {
+        outp = a.out1; ld = a.Cout - a.cout_split; nn = n - a.cout_split;
+      } else {
+        ld = a.cout_split;
+      }
+    }
+    const bool nok = n < a.Cout;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+      size_t off[16];
+      bool ok[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
         const int p = (wave * 2 + mt) * 32 + mrow;
         const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        if (oy < a.Ho && ox < a.Wo) a.out[(((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + n] = (__bf16)acc[mt][j][i];
+        ok[i] = nok && oy < a.Ho && ox < a.Wo;
+        off[i] = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld + nn;
       }
+      if (a.accumulate && outp == a.out) {
+        float prev[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[i] = ok[i] ? (float)outp[off[i]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (ok[i]) outp[off[i]] = (__bf16)(acc[mt][j][i] + prev[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (ok[i]) {
+            const float v = acc[mt][j][i];
+            s1[j] += v;
+            s2[j] += v * v;
+            outp[off[i]] = (__bf16)v;
+          }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);  // [2][4 waves][TN]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (h == 0) {
+        red[wave * TN + 32 * j + r] = t1;
+        red[4 * TN + wave * TN + 32 * j + r] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * TN) {
+      const int which = tid / TN, c = tid % TN;
+      if (n0 + c < a.Cout) {
+        const float* rr = red + which * 4 * TN + c;
+        a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = (rr[0] + rr[TN]) + (rr[2 * TN] + rr[3 * TN]);
+      }
+    }
   }
 }
 
 static int bf_validate(const dt_conv_desc* d) {
   DT_REQUIRE(d != nullptr, "conv_bf16: null descriptor");
   DT_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv_bf16: bad sizes");
-  DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && d->stride == 2),
+  DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && (d->stride == 2 || d->stride == 1)),
              "conv_bf16: ksize/stride (%d,%d) unsupported", d->ksize, d->stride);
   DT_REQUIRE((d->C0 & 7) == 0 && (d->C1 & 7) == 0, "conv_bf16: channels must be multiples of 8");
   DT_REQUIRE(d->C1 == 0 || (d->C0 % BF_CK) == 0, "conv_bf16: concat needs C0 %% 32 == 0");
-  DT_REQUIRE(d->mode0 == 0 || d->mode0 == 1, "conv_bf16: mode0 %d unsupported", d->mode0);
+  DT_REQUIRE(d->mode0 >= 0 && d->mode0 <= 2, "conv_bf16: mode0 %d unsupported", d->mode0);
   DT_REQUIRE(d->mode0 == 0 || ((d->Hin & 1) == 0 && (d->Win & 1) == 0), "conv_bf16: mode0 needs even Hin/Win");
-  DT_REQUIRE(d->cout_split == 0 && d->accumulate == 0, "conv_bf16: split/accumulate not built");
+  DT_REQUIRE(d->cout_split == 0 || ((d->cout_split % 32) == 0 && d->cout_split < d->Cout),
+             "conv_bf16: cout_split must be a multiple of 32 below Cout");
   const int ho = (d->Hin + 2 * d->pad - d->ksize) / d->stride + 1, wo = (d->Win + 2 * d->pad - d->ksize) / d->stride + 1;
   DT_REQUIRE(ho == d->Ho && wo == d->Wo, "conv_bf16: Ho/Wo mismatch");
   return DT_OK;
@@ -243,21 +302,39 @@ static int bf_dispatch(const ConvBfArgs& a, int tw, int tn, hipStream_t st) {
   return bf_launch<KS, STRIDE, 8, 32>(a, st);
 }
 
+static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_) {
+  const int tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
+  int tn = d->Cout >= 64 ? 64 : 32;
+  if (d->cout_split > 0 && (d->cout_split % 64) != 0) tn = 32;
+  if (tn == 64) {
+    const long wgs = (long)d->B * dt_cdiv(d->Ho, 256 / tw) * dt_cdiv(d->Wo, tw) * dt_cdiv(d->Cout, 64);
+    if (wgs < 512) tn = 32;
+  }
+  *tw_ = tw;
+  *tn_ = tn;
+}
+
+extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
+  if (bf_validate(d) != DT_OK) return DT_EINVAL;
+  int tw, tn;
+  bf_cfg(d, &tw, &tn);
+  return d->B * dt_cdiv(d->Ho, 256 / tw) * dt_cdiv(d->Wo, tw);
+}
+
 extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16,
-                              void* out, const float* in_scale, const float* in_shift, void* stream) {
+                              void* out, void* out1, float* stats, const float* in_scale, const float* in_shift,
+                              void* stream) {
   int rc = bf_validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && w_bf16 && out, "conv_bf16: null pointer");
   DT_REQUIRE(d->C1 == 0 || src1, "conv_bf16: src1 missing");
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_bf16: in_scale/in_shift must come together");
   DT_REQUIRE(in_scale == nullptr || d->C0 <= BF_TF_MAXC, "conv_bf16: input transform needs C0 <= %d", BF_TF_MAXC);
-  const int tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
-  int tn = d->Cout >= 64 ? 64 : 32;
-  if (tn == 64) {
-    const long wgs = (long)d->B * dt_cdiv(d->Ho, 256 / tw) * dt_cdiv(d->Wo, tw) * dt_cdiv(d->Cout, 64);
-    if (wgs < 512) tn = 32;
-  }
+  DT_REQUIRE(d->cout_split == 0 || out1, "conv_bf16: out1 missing");
+  int tw, tn;
+  bf_cfg(d, &tw, &tn);
   ConvBfArgs a;
+  a.out1 = (__bf16*)out1; a.stats = stats; a.cout_split = d->cout_split; a.accumulate = d->accumulate;
   a.src0 = (const __bf16*)src0; a.src1 = (const __bf16*)src1; a.w = (const __bf16*)w_bf16;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out = (__bf16*)out;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
@@ -267,6 +344,7 @@ extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const voi
   hipStream_t st = (hipStream_t)stream;
   if (d->ksize == 3 && d->stride == 1) return bf_dispatch<3, 1>(a, tw, tn, st);
   if (d->ksize == 3 && d->stride == 2) return bf_dispatch<3, 2>(a, tw, tn, st);
+  if (d->ksize == 1 && d->stride == 1) return bf_dispatch<1, 1>(a, tw, tn, st);
   return bf_dispatch<1, 2>(a, tw, tn, st);
 }
 
@@ -292,6 +370,29 @@ extern "C" int dt_pack_weights_bf16(const float* w_hwio, void* out, int ksize, i
   dim3 grid(dt_cdiv(Cout, 32), dt_cdiv(Cin, 32), ksize * ksize);
   hipLaunchKernelGGL(pack_weights_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, w_hwio, (__bf16*)out,
                      ksize * ksize, Cin, Cout);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// data-gradient weights: the dgrad conv has Cout_d = Cin, Cin_d = Cout, so its [tap'][Cout_d][Cin_d] image is the
+// HWIO tensor itself with the taps reversed — one elementwise fp32 -> bf16 pass
+__global__ void pack_dgrad_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int taps,
+                                               int64_t per_tap) {
+  const int64_t total = (int64_t)taps * per_tap;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t tap = i / per_tap, e = i - tap * per_tap;
+    out[i] = (__bf16)w[(taps - 1 - tap) * per_tap + e];
+  }
+}
+
+extern "C" int dt_pack_dgrad_weights_bf16(const float* w_hwio, void* out, int ksize, int Cin, int Cout, void* stream) {
+  DT_REQUIRE(w_hwio && out && ksize > 0 && Cin > 0 && Cout > 0, "pack_dgrad_weights_bf16: bad args");
+  const int64_t per_tap = (int64_t)Cin * Cout;
+  int64_t g = (per_tap * ksize * ksize + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pack_dgrad_weights_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_hwio,
+                     (__bf16*)out, ksize * ksize, per_tap);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -426,6 +527,269 @@ extern "C" int dt_bf16_to_f32(const void* x, float* out, int64_t n, void* stream
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x,
                      (f32x4*)out, n / 8);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ weight gradient, bf16 operands
+// dW[tap][ci][co] (fp32) = sum_pixels x[pix+tap][ci] * dy[pix][co] on v_mfma_f32_32x32x16_bf16 with K = 16 pixels.
+// Both operands need 8 consecutive PIXELS per lane for a fixed channel, i.e. the transpose of the NHWC tile:
+// the tiles are staged pixel-major (coalesced from HBM) and read with ds_read_b64_tr_b16, which hands every
+// 16-lane group a 4-pixel x 16-channel block column-major (cdna_hip_programming.md T10) — no transposed copy.
+// Tap shifts move whole pixel rows of the LDS image, so every transposed read stays 8-byte aligned.
+struct WgradBfArgs {
+  const __bf16* src0;
+  const __bf16* src1;
+  const float* in_scale;
+  const float* in_shift;
+  const __bf16* dy;
+  float* ws;  // [parts][taps][Cin][Cout] fp32 slabs
+  int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, T, ci_blocks, co_blocks, ksplit;
+};
+
+#define WB_PITCH 72   // bf16 elements per LDS row (64 used): 144 bytes (multiple of 8 for the transposed reads)
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+template <int KS, int STRIDE, int TW, bool TF>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfArgs a) {
+  constexpr int TPX = 128, TH = TPX / TW;
+  constexpr int LS = (KS == 1) ? 1 : STRIDE, GS = (KS == 1) ? STRIDE : 1;
+  constexpr int HALO_H = (TH - 1) * LS + KS, HALO_W = (TW - 1) * LS + KS;
+  constexpr int TAPS = KS * KS;
+  constexpr int X_ROWS = HALO_H * HALO_W;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[(X_ROWS + TPX) * WB_PITCH];
+  __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 128 : 4];
+  __bf16* lx = lds;
+  __bf16* ly = lds + X_ROWS * WB_PITCH;
+  const int wgid = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int blk = wgid % (a.ci_blocks * a.co_blocks), ks = wgid / (a.ci_blocks * a.co_blocks);
+  const int ci0 = (blk / a.co_blocks) * 64, co0 = (blk % a.co_blocks) * 64;
+  const int Cin = a.C0 + a.C1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wci = wave >> 1, wco = wave & 1;
+  // transposed-read lane roles: group g = lane>>4 -> channel half (g&1), pixel half h = lane>>5; q,p inside the group
+  const int h = lane >> 5, gsel = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int xlane = (8 * h + q4) * LS * WB_PITCH + wci * 32 + 16 * gsel + 4 * p4;
+  const int ylane = (8 * h + q4) * WB_PITCH + wco * 32 + 16 * gsel + 4 * p4;
+  if constexpr (TF) {
+    if (tid < 64 && ci0 + tid < a.C0) {
+      lds_tf[tid] = a.in_scale[ci0 + tid];
+      lds_tf[64 + tid] = a.in_shift[ci0 + tid];
+    }
+  }
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // staging: 8 x 16-byte segments (8 channels) per pixel row
+  constexpr int X_TOTAL = X_ROWS * 8, X_IT = (X_TOTAL + 255) / 256;
+  constexpr int Y_TOTAL = TPX * 8, Y_IT = (Y_TOTAL + 255) / 256;
+  const int q8 = tid & 7, prow0 = tid >> 3;
+  const int cx = ci0 + 8 * q8;
+  const bool x_use0 = cx < a.C0;
+  const __bf16* xsrc = x_use0 ? a.src0 : a.src1;
+  const int xC = x_use0 ? a.C0 : a.C1, xcc = x_use0 ? cx : cx - a.C0, xmode = x_use0 ? a.mode0 : 0;
+  const int xHs = xmode ? (a.Hin >> 1) : a.Hin, xWs = xmode ? (a.Win >> 1) : a.Win;
+  const bool x_ch_ok = cx < Cin;
+  const bool x_tf = TF && x_use0 && x_ch_ok;
+  const int cy = co0 + 8 * q8;
+  const bool y_ch_ok = cy < a.Cout;
+
+  for (int tile = ks; tile < a.T; tile += a.ksplit) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - a.pad, ix0 = ox0 * STRIDE - a.pad;
+    f32x4 rx[X_IT], ry[Y_IT];
+    unsigned xvalid = 0;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int pix = prow0 + it * 32;
+      const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
+      const int iy = iy0 + hy * GS, ix = ix0 + hx * GS;
+      bool ok = x_ch_ok && pix < X_ROWS && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      if (xmode == 2) ok = ok && (((iy | ix) & 1) == 0);
+      const int sy = xmode ? (iy >> 1) : iy, sx = xmode ? (ix >> 1) : ix;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(xsrc + (((size_t)b * xHs + sy) * xWs + sx) * xC + xcc);
+      xvalid |= (ok ? 1u : 0u) << it;
+      rx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int pix = prow0 + it * 32;
+      const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y_ch_ok && pix < TPX && oy < a.Ho && ox < a.Wo)
+        v = *reinterpret_cast<const f32x4*>(a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + cy);
+      ry[it] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int pix = prow0 + it * 32;
+      if (pix < X_ROWS) {
+        f32x4 raw = rx[it];
+        if (TF && x_tf && ((xvalid >> it) & 1u)) {
+          bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float f = (float)v[k] * lds_tf[8 * q8 + k] + lds_tf[64 + 8 * q8 + k];
+            f = f < 0.f ? 0.f : f;
+            v[k] = (__bf16)f;
+          }
+          raw = *reinterpret_cast<f32x4*>(&v);
+        }
+        *reinterpret_cast<f32x4*>(lx + pix * WB_PITCH + 8 * q8) = raw;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int pix = prow0 + it * 32;
+      if (pix < TPX) *reinterpret_cast<f32x4*>(ly + pix * WB_PITCH + 8 * q8) = ry[it];
+    }
+    __syncthreads();
+    typedef bf16x4v __attribute__((address_space(3))) * lds_ptr;
+#pragma unroll
+    for (int row = 0; row < TH; ++row) {
+#pragma unroll
+      for (int xs = 0; xs < TW / 16; ++xs) {
+        // B fragment: dy pixels (row, 16*xs + 8h .. +7), channels of this wave's co tile
+        bf16x8 bv;
+        {
+          const int e = ylane + (row * TW + 16 * xs) * WB_PITCH;
+          const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(ly + e));
+          const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(ly + e + 4 * WB_PITCH));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            bv[k] = lo[k];
+            bv[4 + k] = hi[k];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int kh = t / KS, kw = t % KS;
+          const int e = xlane + ((row * LS + kh) * HALO_W + 16 * xs * LS + kw) * WB_PITCH;
+          const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lx + e));
+          const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lx + e + 4 * LS * WB_PITCH));
+          bf16x8 av;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            av[k] = lo[k];
+            av[4 + k] = hi[k];
+          }
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int part = ks;
+  const int r = lane & 31;
+  const int co = co0 + wco * 32 + r;
+  if (co < a.Cout) {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (ci < Cin) a.ws[(((size_t)part * TAPS + t) * Cin + ci) * a.Cout + co] = acc[t][i];
+      }
+  }
+}
+
+static int wb_cfg(const dt_conv_desc* d, int* tw, int* ksplit, int* T, int* cib, int* cob) {
+  const int Cin = d->C0 + d->C1;
+  *tw = d->Wo > 16 ? 32 : 16;
+  *cib = dt_cdiv(Cin, 64);
+  *cob = dt_cdiv(d->Cout, 64);
+  const int th = 128 / *tw;
+  *T = d->B * dt_cdiv(d->Ho, th) * dt_cdiv(d->Wo, *tw);
+  int ks = 512 / (*cib * *cob);
+  if (ks < 1) ks = 1;
+  if (ks > *T) ks = *T;
+  *ksplit = ks;
+  return DT_OK;
+}
+
+static int wb_validate(const dt_conv_desc* d) {
+  DT_REQUIRE(d != nullptr, "wgrad_bf16: null descriptor");
+  DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && d->stride == 2),
+             "wgrad_bf16: ksize/stride (%d,%d) unsupported", d->ksize, d->stride);
+  DT_REQUIRE((d->C0 & 7) == 0 && (d->C1 & 7) == 0 && (d->Cout & 7) == 0, "wgrad_bf16: channels must be multiples of 8");
+  DT_REQUIRE(d->mode0 >= 0 && d->mode0 <= 1, "wgrad_bf16: mode0");
+  const int ho = (d->Hin + 2 * d->pad - d->ksize) / d->stride + 1, wo = (d->Win + 2 * d->pad - d->ksize) / d->stride + 1;
+  DT_REQUIRE(ho == d->Ho && wo == d->Wo, "wgrad_bf16: Ho/Wo mismatch");
+  return DT_OK;
+}
+
+extern "C" size_t dt_conv2d_wgrad_bf16_workspace(const dt_conv_desc* d) {
+  if (wb_validate(d) != DT_OK) return 0;
+  int tw, ks, T, cib, cob;
+  wb_cfg(d, &tw, &ks, &T, &cib, &cob);
+  const size_t E = (size_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
+  const int rb = ks > 16 ? dt_cdiv(ks, 16) : 1;
+  const int parts2 = ks > 16 ? dt_cdiv(ks, rb) : 0;
+  return ((size_t)ks + parts2) * E * sizeof(float);
+}
+
+__global__ __launch_bounds__(256) void wgrad_bf16_final_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                               int parts, int64_t E) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
+    double s = 0.0;
+    for (int p = 0; p < parts; ++p) s += (double)ws[(size_t)p * E + e];
+    dw[e] = (float)s;
+  }
+}
+
+template <int KS, int STRIDE, int TW>
+static int wb_launch(const WgradBfArgs& a, int grid, hipStream_t st) {
+  if (a.in_scale != nullptr)
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, true>), dim3(grid), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, false>), dim3(grid), dim3(256), 0, st, a);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* dy,
+                                    float* dw_hwio, float* workspace, size_t workspace_bytes, const float* in_scale,
+                                    const float* in_shift, void* stream) {
+  int rc = wb_validate(d);
+  if (rc != DT_OK) return rc;
+  DT_REQUIRE(src0 && dy && dw_hwio && workspace, "wgrad_bf16: null pointer");
+  DT_REQUIRE(d->C1 == 0 || src1, "wgrad_bf16: src1 missing");
+  DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wgrad_bf16: in_scale/in_shift must come together");
+  DT_REQUIRE(workspace_bytes >= dt_conv2d_wgrad_bf16_workspace(d), "wgrad_bf16: workspace too small");
+  WgradBfArgs a;
+  int tw;
+  wb_cfg(d, &tw, &a.ksplit, &a.T, &a.ci_blocks, &a.co_blocks);
+  a.src0 = (const __bf16*)src0; a.src1 = (const __bf16*)src1; a.dy = (const __bf16*)dy; a.ws = workspace;
+  a.in_scale = in_scale; a.in_shift = in_shift;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.pad = d->pad;
+  a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 128 / tw);
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = a.ci_blocks * a.co_blocks * a.ksplit;
+  if (d->ksize == 3 && d->stride == 1) rc = tw == 32 ? wb_launch<3, 1, 32>(a, grid, st) : wb_launch<3, 1, 16>(a, grid, st);
+  else if (d->ksize == 3) rc = tw == 32 ? wb_launch<3, 2, 32>(a, grid, st) : wb_launch<3, 2, 16>(a, grid, st);
+  else rc = tw == 32 ? wb_launch<1, 2, 32>(a, grid, st) : wb_launch<1, 2, 16>(a, grid, st);
+  if (rc != DT_OK) return rc;
+  const int64_t E = (int64_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
+  const float* slabs = workspace;
+  int nslabs = a.ksplit;
+  if (a.ksplit > 16) {
+    const int rb = dt_cdiv(a.ksplit, 16);
+    float* stage = workspace + (size_t)a.ksplit * E;
+    rc = dt_reduce_rows_launch(workspace, stage, 1, a.ksplit, (int)E, rb, st);
+    if (rc != DT_OK) return rc;
+    slabs = stage;
+    nslabs = dt_cdiv(a.ksplit, rb);
+  }
+  int64_t g = (E + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(wgrad_bf16_final_kernel, dim3((unsigned)g), dim3(256), 0, st, slabs, dw_hwio, nslabs, E);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

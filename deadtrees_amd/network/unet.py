@@ -291,8 +291,8 @@ class UNetEngine:
             desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
             y = torch.empty((B, Ho, Wo, c.cout), dtype=bf, device=dev)
             _lib.check(lib.dt_conv2d_bf16(C.byref(desc), _p(src0), _p(src1), _p(wb[c.w_off:c.w_off + c.w_size]), _p(y),
-                                          _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None, st),
-                       "dt_conv2d_bf16")
+                                          None, None, _p(in_ss[0]) if in_ss else None,
+                                          _p(in_ss[1]) if in_ss else None, st), "dt_conv2d_bf16")
             return y, Ho, Wo, affine(c)
 
         def bn_act(y, ss, res=None, res_ss=None, y_f32=False):

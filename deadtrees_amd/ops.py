@@ -223,6 +223,68 @@ def head_bwd(x, w_ohwi, dlogits):
     return dx, dw, db
 
 
+def conv2d_bf16(src0, w_packed, k, stride, pad, cout, src1=None, mode0=0, split=0, out0=None, out1=None,
+                accumulate=False, want_stats=False, in_scale=None, in_shift=None):
+    """bf16 NHWC conv (fp32 accumulate) through dt_conv2d_bf16; w_packed = [k*k, cout, cin] bf16."""
+    _gpu(src0, src1, w_packed)
+    lib = _lib.load()
+    B, C0 = src0.shape[0], src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    Hin, Win = (src0.shape[1], src0.shape[2]) if mode0 == 0 else (2 * src0.shape[1], 2 * src0.shape[2])
+    d = conv_desc(B, Hin, Win, C0, C1, mode0, cout, k, stride, pad, split, 1 if accumulate else 0)
+    dev, bf = src0.device, torch.bfloat16
+    if out0 is None:
+        out0 = torch.empty((B, d.Ho, d.Wo, split if split else cout), dtype=bf, device=dev)
+    if split and out1 is None:
+        out1 = torch.empty((B, d.Ho, d.Wo, cout - split), dtype=bf, device=dev)
+    stats = None
+    if want_stats:
+        P = lib.dt_conv2d_bf16_stat_rows(C.byref(d))
+        if P <= 0:
+            raise RuntimeError(lib.dt_last_error().decode())
+        stats = torch.empty(lib.dt_bn_stats_floats(P, cout), dtype=torch.float32, device=dev)
+    _lib.check(lib.dt_conv2d_bf16(C.byref(d), _p(src0), _p(src1), _p(w_packed), _p(out0), _p(out1), _p(stats),
+                                  _p(in_scale), _p(in_shift), _st()), "dt_conv2d_bf16")
+    if stats is not None:
+        stats = stats[:2 * P * cout].view(2, P, cout)
+    return out0, out1, stats
+
+
+def pack_weights_bf16(w_hwio, dgrad=False):
+    """fp32 HWIO -> bf16 [taps][Cout][Cin] (forward) or the data-gradient image [taps][Cin][Cout] (taps reversed)"""
+    _gpu(w_hwio)
+    k, _, cin, cout = w_hwio.shape
+    lib = _lib.load()
+    if dgrad:
+        out = torch.empty((k * k, cin, cout), dtype=torch.bfloat16, device=w_hwio.device)
+        _lib.check(lib.dt_pack_dgrad_weights_bf16(_p(w_hwio.contiguous()), _p(out), k, cin, cout, _st()),
+                   "dt_pack_dgrad_weights_bf16")
+    else:
+        out = torch.empty((k * k, cout, cin), dtype=torch.bfloat16, device=w_hwio.device)
+        _lib.check(lib.dt_pack_weights_bf16(_p(w_hwio.contiguous()), _p(out), k, cin, cout, _st()),
+                   "dt_pack_weights_bf16")
+    return out
+
+
+def conv2d_wgrad_bf16(src0, dy, k, stride, pad, src1=None, mode0=0, in_scale=None, in_shift=None):
+    _gpu(src0, src1, dy)
+    lib = _lib.load()
+    B, C0 = src0.shape[0], src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    Hin, Win = (src0.shape[1], src0.shape[2]) if mode0 == 0 else (2 * src0.shape[1], 2 * src0.shape[2])
+    Cout = dy.shape[-1]
+    d = conv_desc(B, Hin, Win, C0, C1, mode0, Cout, k, stride, pad)
+    assert (d.Ho, d.Wo) == (dy.shape[1], dy.shape[2])
+    nbytes = lib.dt_conv2d_wgrad_bf16_workspace(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError(lib.dt_last_error().decode())
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+    dw = torch.empty((k, k, C0 + C1, Cout), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.dt_conv2d_wgrad_bf16(C.byref(d), _p(src0), _p(src1), _p(dy.contiguous()), _p(dw), _p(ws), nbytes,
+                                        _p(in_scale), _p(in_shift), _st()), "dt_conv2d_wgrad_bf16")
+    return dw
+
+
 def confusion_matrix(pred, target, lu=None, K=2, counts=None):
     """counts int64 [2,K,K] (+=): [0] all pixels, [1] pixels with lu == 1; rows target, cols prediction."""
     _gpu(pred, target, lu)

@@ -177,10 +177,20 @@ int dt_confusion_matrix(const int64_t* pred_i64, const uint8_t* pred_u8, const i
 /* ------------------------------------------------------------------ bf16 storage / fp32 accumulate (inference leg)
  * BASELINE configs[2] precision: activations NHWC bf16, weights [tap][Cout][Cin] bf16 (dt_pack_weights_bf16),
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulators, one rounding at the store.  Same descriptor semantics as
- * dt_conv2d (mode0 0/1, concat, fused input BatchNorm-apply + ReLU); no split/accumulate/statistics yet. */
+ * dt_conv2d (mode0 0/1/2, concat, split outputs, accumulate, BatchNorm partial statistics from the fp32
+ * accumulators, fused input BatchNorm-apply + ReLU). */
+int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d);
 int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16, void* out,
-                   const float* in_scale, const float* in_shift, void* stream);
+                   void* out1, float* stats, const float* in_scale, const float* in_shift, void* stream);
 int dt_pack_weights_bf16(const float* w_hwio, void* out_bf16, int ksize, int Cin, int Cout, void* stream);
+/* weights of the bf16 data-gradient convolution ([tap'][Cin][Cout] = HWIO with the taps reversed) */
+int dt_pack_dgrad_weights_bf16(const float* w_hwio, void* out_bf16, int ksize, int Cin, int Cout, void* stream);
+/* fp32 dW[kh][kw][ci][co] from bf16 x (same virtual-input modes as dt_conv2d_wgrad) and bf16 dy; operands are
+ * transposed out of the pixel-major LDS tiles by ds_read_b64_tr_b16; split-K slabs reduced in fixed order. */
+size_t dt_conv2d_wgrad_bf16_workspace(const dt_conv_desc* d);
+int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* dy, float* dw_hwio,
+                         float* workspace, size_t workspace_bytes, const float* in_scale, const float* in_shift,
+                         void* stream);
 /* out(bf16) = act(y*scale+shift + res'), y fp32 (y_is_f32) or bf16, res bf16 (optional affine) */
 int dt_bn_act_bf16(const void* y, int y_is_f32, const float* scale, const float* shift, const void* res,
                    const float* rscale, const float* rshift, void* out, int64_t n_pix, int C, int relu, void* stream);

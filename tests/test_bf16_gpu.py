@@ -1,0 +1,136 @@
+"""bf16-storage / fp32-accumulate kernels against fp64 references computed on the SAME bf16-rounded inputs.
+Tolerance: one bf16 rounding of the output (2^-8 relative) on top of fp32 accumulation."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _ops():
+    from deadtrees_amd import ops
+    return ops
+
+
+def bf(t):  # NCHW fp32 cpu -> NHWC bf16 gpu, and its exact fp64 value
+    q = t.to(BF)
+    return q.permute(0, 2, 3, 1).contiguous().to(DEV), q.double()
+
+
+def to_nchw(t):
+    return t.detach().float().cpu().permute(0, 3, 1, 2).double()
+
+
+def close_bf16(got, ref, extra=0.0):
+    err = (got - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + ref.abs().max() * (2.0 ** -9 + extra)
+    assert bool((err <= tol).all()), float((err / tol).max())
+
+
+CASES = [(2, 32, 32, 64, 64, 3, 1, 1), (1, 40, 24, 16, 16, 3, 1, 1), (2, 16, 16, 128, 96, 3, 1, 1),
+         (2, 8, 8, 32, 48, 3, 1, 1), (2, 32, 32, 64, 128, 3, 2, 1), (2, 32, 32, 64, 128, 1, 2, 0),
+         (1, 34, 70, 512, 64, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
+def test_conv_bf16_forward_and_stats(B, H, W, Cin, Cout, k, s, p):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    xg, x64 = bf(x)
+    w_hwio = w.permute(2, 3, 1, 0).contiguous().to(DEV)
+    wp = ops.pack_weights_bf16(w_hwio)
+    w64 = w.to(BF).double()
+    ref = F.conv2d(x64, w64, stride=s, padding=p)
+    y, _, stats = ops.conv2d_bf16(xg, wp, k, s, p, Cout, want_stats=True)
+    close_bf16(to_nchw(y), ref)
+    np.testing.assert_allclose(stats[0].double().sum(0).cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-4,
+                               atol=1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max()))
+    np.testing.assert_allclose(stats[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4)
+
+
+def test_conv_bf16_upsample_concat_transform_split_accumulate():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, h, w_, C0, C1, Cout = 2, 10, 12, 64, 32, 96
+    a = torch.randn((B, C0, h, w_), generator=g)
+    skip = torch.randn((B, C1, 2 * h, 2 * w_), generator=g)
+    sc = 1 + 0.3 * torch.randn(C0, generator=g)
+    sh = 0.3 * torch.randn(C0, generator=g) + 0.4
+    wt = torch.randn((Cout, C0 + C1, 3, 3), generator=g) * 0.05
+    ag, a64 = bf(a)
+    sg, s64 = bf(skip)
+    # the kernel rounds the transformed activation to bf16 while staging it
+    z = F.relu(a64.float() * sc[None, :, None, None] + sh[None, :, None, None]).to(BF).double()
+    xin = torch.cat([F.interpolate(z, scale_factor=2, mode="nearest"), s64], dim=1)
+    ref = F.conv2d(xin, wt.to(BF).double(), padding=1)
+    wp = ops.pack_weights_bf16(wt.permute(2, 3, 1, 0).contiguous().to(DEV))
+    y, _, _ = ops.conv2d_bf16(ag, wp, 3, 1, 1, Cout, src1=sg, mode0=1, in_scale=sc.to(DEV), in_shift=sh.to(DEV))
+    close_bf16(to_nchw(y), ref)
+    base = torch.randn((B, 2 * h, 2 * w_, 64), generator=g).to(BF).to(DEV)
+    o0, o1, _ = ops.conv2d_bf16(ag, wp, 3, 1, 1, Cout, src1=sg, mode0=1, in_scale=sc.to(DEV), in_shift=sh.to(DEV),
+                                split=64, out0=base.clone(), accumulate=True)
+    close_bf16(to_nchw(o0), ref[:, :64] + to_nchw(base))
+    close_bf16(to_nchw(o1), ref[:, 64:])
+
+
+@pytest.mark.parametrize("k,p", [(3, 1), (1, 0)])
+def test_conv_bf16_stride2_data_gradient(k, p):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = 2, 16, 24, 64, 128
+    wt = (torch.randn((Cout, Cin, k, k), generator=g) * 0.05).to(BF).double()
+    x = torch.randn((B, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, wt, stride=2, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    dyg, dy64 = bf(dy)
+    y.backward(dy64)
+    wd = ops.pack_weights_bf16(wt.float().permute(2, 3, 1, 0).contiguous().to(DEV), dgrad=True)
+    dx, _, _ = ops.conv2d_bf16(dyg, wd, k, 1, k - 1 - p, Cin, mode0=2)
+    close_bf16(to_nchw(dx), x.grad)
+
+
+WG_CASES = [(2, 32, 32, 64, 64, 3, 1, 1), (2, 16, 16, 128, 256, 3, 1, 1), (1, 40, 24, 16, 16, 3, 1, 1),
+            (2, 32, 64, 32, 16, 3, 1, 1), (2, 8, 8, 64, 32, 3, 1, 1), (2, 32, 32, 64, 128, 3, 2, 1),
+            (2, 32, 32, 64, 128, 1, 2, 0)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", WG_CASES)
+def test_wgrad_bf16(B, H, W, Cin, Cout, k, s, p):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H + Cin * 7 + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    xg, x64 = bf(x)
+    wt = (torch.randn((Cout, Cin, k, k), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(x64, wt, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    dyg, dy64 = bf(dy)
+    y.backward(dy64)
+    dw = ops.conv2d_wgrad_bf16(xg, dyg, k, s, p)
+    got = dw.cpu().permute(3, 2, 0, 1).double()
+    assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
+
+
+def test_wgrad_bf16_upsample_concat_transform():
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    B, h, w_, C0, C1, Cout = 2, 8, 8, 64, 64, 32
+    a = torch.randn((B, C0, h, w_), generator=g)
+    skip = torch.randn((B, C1, 2 * h, 2 * w_), generator=g)
+    sc = 1 + 0.3 * torch.randn(C0, generator=g)
+    sh = 0.3 * torch.randn(C0, generator=g) + 0.4
+    ag, a64 = bf(a)
+    sg, s64 = bf(skip)
+    z = F.relu(a64.float() * sc[None, :, None, None] + sh[None, :, None, None]).to(BF).double()
+    wt = (torch.randn((Cout, C0 + C1, 3, 3), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(torch.cat([F.interpolate(z, scale_factor=2, mode="nearest"), s64], 1), wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    dyg, dy64 = bf(dy)
+    y.backward(dy64)
+    dw = ops.conv2d_wgrad_bf16(ag, dyg, 3, 1, 1, src1=sg, mode0=1, in_scale=sc.to(DEV), in_shift=sh.to(DEV))
+    got = dw.cpu().permute(3, 2, 0, 1).double()
+    assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
