@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32", help="inference mode only")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE configs[1] (headline); bf16 = configs[2] (bf16 storage, fp32 accumulate)")
     ap.add_argument("--mode", choices=["train", "infer"], default="train",
                     help="train = BASELINE configs[1] (the headline metric); infer = tiled-inference forward "
                          "(uint8 tiles -> uint8 class maps, BASELINE configs[4] per-GPU leg)")
@@ -79,7 +80,8 @@ def main():
     model.to(dev)
     if args.mode == "infer":
         return infer_bench(args, model, dev, world, rank, distributed)
-    tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed)
+    tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed,
+                    precision=args.precision)
     tr.broadcast_parameters(0)
     img, mask = synth_batch(B, S, S, 3, 2, seed=1234 + rank)
     img, mask = img.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
@@ -141,17 +143,21 @@ def main():
             except Exception:
                 pass
     per_gpu_tiles_s = B * args.steps / wall
+    peak_tf = PEAK_FP32_TFLOPS if args.precision == "fp32" else 2500.0   # dense bf16 MFMA peak
+    bytes_per_tile = BYTES_PER_TILE_TRAIN if args.precision == "fp32" else 462.2e6
     out = {
         "metric": "512x512 RGB tiles/sec (train fwd+bwd)", "value": round(value, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: reference U-Net (smp Unet/resnet34 topology) fp32 train step, "
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "bf16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
+        "config": {"workload": ("configs[1]" if args.precision == "fp32" else "configs[2]") +
+                               f": reference U-Net (smp Unet/resnet34 topology) {args.precision} train step, "
                                f"batch {B}/GPU, {S}x{S}x3 tiles, GDICE+FOCAL, clip 0.5, Adam 3e-4",
                    "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
         "loss": round(float(loss), 6),
         "whole_net": {"tflops": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12, 2),
-                      "mfma_frac": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12 / PEAK_FP32_TFLOPS, 4),
-                      "hbm_frac_step": round(per_gpu_tiles_s * BYTES_PER_TILE_TRAIN / 1e9 / PEAK_HBM_GBS, 4),
+                      "mfma_frac": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12 / peak_tf, 4),
+                      "hbm_frac_step": round(per_gpu_tiles_s * bytes_per_tile / 1e9 / PEAK_HBM_GBS, 4),
                       "conv_fwd_dgrad_share_of_step": round(conv_time / (float(e0.elapsed_time(e1)) * 1e-3), 4)},
         "roofline": roof,
     }

@@ -65,3 +65,5 @@ extern "C" int dt_conv2d_wgrad_n16_supported(const dt_conv_desc* d);
 int dt_wgrad_n16_cfg(const dt_conv_desc* d, int* ksplit, int* parts);
 int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* dy, float* ws, const float* in_scale,
                         const float* in_shift, hipStream_t st);
+
+int dt_bn_bwd_finish_sums(float* red, int P, int C, float* dgamma, float* dbeta, hipStream_t st);

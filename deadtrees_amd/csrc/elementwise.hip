@@ -321,6 +321,21 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
   }
 }
 
+// partial rows red[2][P][C] (+ scratch tail) -> dgamma, dbeta : two-stage, fixed order (shared with the bf16 path)
+int dt_bn_bwd_finish_sums(float* red, int P, int C, float* dgamma, float* dbeta, hipStream_t st) {
+  if (P > BN_STAGE1_MIN_ROWS) {
+    const int PB = dt_reduce_rows_out(P, BN_STAGE1_RB);
+    float* scratch = red + (size_t)2 * P * C;
+    int rc = dt_reduce_rows_launch(red, scratch, 2, P, C, BN_STAGE1_RB, st);
+    if (rc != DT_OK) return rc;
+    red = scratch;
+    P = PB;
+  }
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dt_cdiv(C, 16)), dim3(256), 0, st, red, P, C, dgamma, dbeta);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4* __restrict__ dout, const f32x4* __restrict__ out_act, const f32x4* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -365,16 +380,8 @@ extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const fl
                  (C & 3) == 0 && P > 0,
              "bn_bwd_apply: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (P > BN_STAGE1_MIN_ROWS) {
-    const int PB = dt_reduce_rows_out(P, BN_STAGE1_RB);
-    float* scratch = red + (size_t)2 * P * C;
-    int rc = dt_reduce_rows_launch(red, scratch, 2, P, C, BN_STAGE1_RB, st);
-    if (rc != DT_OK) return rc;
-    red = scratch;
-    P = PB;
-  }
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(dt_cdiv(C, 16)), dim3(256), 0, st, red, P, C, dgamma, dbeta);
-  DT_LAUNCH_CHECK();
+  int rc0 = dt_bn_bwd_finish_sums(red, P, C, dgamma, dbeta, st);
+  if (rc0 != DT_OK) return rc0;
   const int64_t n4 = n_pix * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, (const f32x4*)dout,
                      (const f32x4*)out_act, (const f32x4*)y, mean, invstd, gamma, dgamma, dbeta, act_scale, act_shift,

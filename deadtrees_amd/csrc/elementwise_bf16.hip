@@ -1,0 +1,349 @@
+// HBM-bound passes of the bf16 training path: BatchNorm backward, max-pool (+argmax) and its backward,
+// nearest-upsample backward, fp32 <-> bf16 shuttles.  8 bf16 (16 B) per lane; every sum in fp32/fp64 with the
+// same deterministic two-stage reductions as the fp32 path (elementwise.hip).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BNB16_RB 256
+
+__device__ __forceinline__ void load8(const bf16x8* p, size_t i, float (&v)[8]) {
+  const bf16x8 a = p[i];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)a[k];
+}
+
+// ------------------------------------------------------------------ BN backward, pass 1
+__global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const bf16x8* __restrict__ dout,
+                                                                 const bf16x8* __restrict__ out_act,
+                                                                 const bf16x8* __restrict__ y,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ act_scale,
+                                                                 const float* __restrict__ act_shift,
+                                                                 float* __restrict__ red, int64_t n_pix, int C8, int Q,
+                                                                 int P) {
+  __shared__ float sh[2][256][9];
+  const int t = threadIdx.x;
+  const int q = t % Q, rl = t / Q, RL = 256 / Q;
+  const int cq = blockIdx.x * Q + q;
+  const int64_t p0 = (int64_t)blockIdx.y * BNB16_RB;
+  int64_t p1 = p0 + BNB16_RB;
+  if (p1 > n_pix) p1 = n_pix;
+  float mu[8], is[8], asc[8], ash[8], sg[8], sx[8];
+  const bool from_y = out_act == nullptr && act_scale != nullptr;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mu[k] = mean[cq * 8 + k];
+    is[k] = invstd[cq * 8 + k];
+    asc[k] = from_y ? act_scale[cq * 8 + k] : 1.f;
+    ash[k] = from_y ? act_shift[cq * 8 + k] : 0.f;
+    sg[k] = sx[k] = 0.f;
+  }
+  for (int64_t p = p0 + rl; p < p1; p += RL) {
+    const size_t o = (size_t)p * C8 + cq;
+    float g[8], yv[8];
+    load8(dout, o, g);
+    load8(y, o, yv);
+    if (out_act) {
+      float a[8];
+      load8(out_act, o, a);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+    } else if (from_y) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        // the consumers saw bf16(relu(y*sc+sh)): the mask is the sign of that rounded value
+        const float a = (float)(__bf16)(yv[k] * asc[k] + ash[k]);
+        g[k] = a > 0.f ? g[k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sg[k] += g[k];
+      sx[k] += g[k] * ((yv[k] - mu[k]) * is[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sh[0][t][k] = sg[k];
+    sh[1][t][k] = sx[k];
+  }
+  __syncthreads();
+  if (rl == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float a = 0.f, b = 0.f;
+      for (int i = 0; i < RL; ++i) {
+        a += sh[0][i * Q + q][k];
+        b += sh[1][i * Q + q][k];
+      }
+      red[(size_t)blockIdx.y * C8 * 8 + cq * 8 + k] = a;
+      red[((size_t)P + blockIdx.y) * C8 * 8 + cq * 8 + k] = b;
+    }
+  }
+}
+
+extern "C" int dt_bn_bwd_rows_bf16(int64_t n_pix) { return dt_cdiv(n_pix, BNB16_RB); }
+
+extern "C" int dt_bn_bwd_reduce_bf16(const void* dout, const void* out_act, const void* y, const float* mean,
+                                     const float* invstd, const float* act_scale, const float* act_shift, float* red,
+                                     int64_t n_pix, int C, void* stream) {
+  DT_REQUIRE(dout && y && mean && invstd && red && n_pix > 0 && C > 0 && (C & 7) == 0, "bn_bwd_reduce_bf16: bad args");
+  const int C8 = C / 8;
+  int Q = 64;
+  while (Q > C8) Q >>= 1;
+  DT_REQUIRE(C8 % Q == 0, "bn_bwd_reduce_bf16: C/8 must be a power of two or a multiple of 64 (C=%d)", C);
+  const int P = dt_bn_bwd_rows_bf16(n_pix);
+  hipLaunchKernelGGL(bn_bwd_reduce_bf16_kernel, dim3(C8 / Q, P), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dout,
+                     (const bf16x8*)out_act, (const bf16x8*)y, mean, invstd, act_scale, act_shift, red, n_pix, C8, Q, P);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ BN backward, pass 2
+__global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(
+    const bf16x8* __restrict__ dout, const bf16x8* __restrict__ out_act, const bf16x8* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ dgamma, const float* __restrict__ dbeta, const float* __restrict__ act_scale,
+    const float* __restrict__ act_shift, bf16x8* __restrict__ dy, bf16x8* __restrict__ dres, int dres_acc, int64_t n8,
+    int C8, float inv_count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const int c = (int)(i % C8) * 8;
+    float g[8], yv[8];
+    load8(dout, i, g);
+    load8(y, i, yv);
+    if (out_act) {
+      float a[8];
+      load8(out_act, i, a);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+    } else if (act_scale) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float a = (float)(__bf16)(yv[k] * act_scale[c + k] + act_shift[c + k]);
+        g[k] = a > 0.f ? g[k] : 0.f;
+      }
+    }
+    if (dres) {
+      bf16x8 o;
+      if (dres_acc) {
+        float prev[8];
+        load8(dres, i, prev);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)(prev[k] + g[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)g[k];
+      }
+      dres[i] = o;
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float is = invstd[c + k];
+      const float xh = (yv[k] - mean[c + k]) * is;
+      o[k] = (__bf16)(gamma[c + k] * is * (g[k] - dbeta[c + k] * inv_count - xh * (dgamma[c + k] * inv_count)));
+    }
+    dy[i] = o;
+  }
+}
+
+extern "C" int dt_bn_bwd_apply_bf16(const void* dout, const void* out_act, const void* y, const float* mean,
+                                    const float* invstd, const float* gamma, const float* act_scale,
+                                    const float* act_shift, float* red, int P, float* dgamma, float* dbeta, void* dy,
+                                    void* dres, int dres_accumulate, int64_t n_pix, int C, void* stream) {
+  DT_REQUIRE(dout && y && mean && invstd && gamma && red && dgamma && dbeta && dy && n_pix > 0 && C > 0 &&
+                 (C & 7) == 0 && P > 0,
+             "bn_bwd_apply_bf16: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dt_bn_bwd_finish_sums(red, P, C, dgamma, dbeta, st);
+  if (rc != DT_OK) return rc;
+  const int64_t n8 = n_pix * C / 8;
+  int64_t g = (n8 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3((unsigned)g), dim3(256), 0, st, (const bf16x8*)dout,
+                     (const bf16x8*)out_act, (const bf16x8*)y, mean, invstd, gamma, dgamma, dbeta, act_scale, act_shift,
+                     (bf16x8*)dy, (bf16x8*)dres, dres_accumulate, n8, C / 8, (float)(1.0 / (double)n_pix));
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ max-pool with argmax / backward
+__global__ __launch_bounds__(256) void maxpool_bf16_amax_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ out,
+                                                                uint2* __restrict__ amax, int B, int H, int W, int C8,
+                                                                int Ho, int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c8 = (int)(i % C8);
+    int64_t rr = i / C8;
+    const int ox = (int)(rr % Wo);
+    rr /= Wo;
+    const int oy = (int)(rr % Ho);
+    const int b = (int)(rr / Ho);
+    float best[8];
+    unsigned bi[8];
+    bool first = true;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * oy - 1 + kh;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = 2 * ox - 1 + kw;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float v[8];
+        load8(x, (((int64_t)b * H + iy) * W + ix) * C8 + c8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (first || v[k] > best[k] || v[k] != v[k]) {
+            best[k] = v[k];
+            bi[k] = kh * 3 + kw;
+          }
+        first = false;
+      }
+    }
+    bf16x8 o;
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = (__bf16)best[k];
+      if (k < 4) lo |= bi[k] << (8 * k); else hi |= bi[k] << (8 * (k - 4));
+    }
+    out[i] = o;
+    amax[i] = make_uint2(lo, hi);
+  }
+}
+
+extern "C" int dt_maxpool3x3s2_bf16_amax(const void* x, void* out, uint8_t* argmax, int B, int H, int W, int C,
+                                         void* stream) {
+  DT_REQUIRE(x && out && argmax && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "maxpool_bf16_amax: bad args");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(maxpool_bf16_amax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x,
+                     (bf16x8*)out, (uint2*)argmax, B, H, W, C / 8, Ho, Wo);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const bf16x8* __restrict__ dout,
+                                                               const uint2* __restrict__ amax, bf16x8* __restrict__ dx,
+                                                               int acc, int B, int H, int W, int C8, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c8 = (int)(i % C8);
+    int64_t rr = i / C8;
+    const int ix = (int)(rr % W);
+    rr /= W;
+    const int iy = (int)(rr % H);
+    const int b = (int)(rr / H);
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int oy = iy >> 1; oy <= ((iy + 1) >> 1); ++oy) {
+      if (oy >= Ho) continue;
+      const int kh = iy - (2 * oy - 1);
+      for (int ox = ix >> 1; ox <= ((ix + 1) >> 1); ++ox) {
+        if (ox >= Wo) continue;
+        const unsigned pos = (unsigned)(kh * 3 + (ix - (2 * ox - 1)));
+        const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * C8 + c8;
+        const uint2 am = amax[o];
+        float d[8];
+        load8(dout, o, d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned a = k < 4 ? (am.x >> (8 * k)) & 0xffu : (am.y >> (8 * (k - 4))) & 0xffu;
+          if (a == pos) g[k] += d[k];
+        }
+      }
+    }
+    bf16x8 o;
+    if (acc) {
+      float prev[8];
+      load8(dx, i, prev);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (__bf16)(prev[k] + g[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (__bf16)g[k];
+    }
+    dx[i] = o;
+  }
+}
+
+extern "C" int dt_maxpool3x3s2_bwd_bf16(const void* dout, const uint8_t* argmax, void* dx, int accumulate, int B, int H,
+                                        int W, int C, void* stream) {
+  DT_REQUIRE(dout && argmax && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "maxpool_bwd_bf16: bad args");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)B * H * W * (C / 8);
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dout,
+                     (const uint2*)argmax, (bf16x8*)dx, accumulate, B, H, W, C / 8, Ho, Wo);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ nearest x2 upsample backward
+__global__ __launch_bounds__(256) void upsample2x_bwd_bf16_kernel(const bf16x8* __restrict__ dup, bf16x8* __restrict__ dx,
+                                                                  int B, int H, int W, int C8) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int W2 = 2 * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c8 = (int)(i % C8);
+    int64_t rr = i / C8;
+    const int x = (int)(rr % W);
+    rr /= W;
+    const int y = (int)(rr % H);
+    const int b = (int)(rr / H);
+    const int64_t base = (((int64_t)b * 2 * H + 2 * y) * W2 + 2 * x) * C8 + c8;
+    float a[8], bq[8], c[8], d[8];
+    load8(dup, base, a);
+    load8(dup, base + C8, bq);
+    load8(dup, base + (int64_t)W2 * C8, c);
+    load8(dup, base + (int64_t)W2 * C8 + C8, d);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (__bf16)((a[k] + bq[k]) + (c[k] + d[k]));
+    dx[i] = o;
+  }
+}
+
+extern "C" int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C, void* stream) {
+  DT_REQUIRE(dup && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "upsample2x_bwd_bf16: bad args");
+  const int64_t total = (int64_t)B * H * W * (C / 8);
+  int64_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(upsample2x_bwd_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16x8*)dup, (bf16x8*)dx, B, H, W, C / 8);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ fp32 -> bf16
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const f32x4* __restrict__ x, bf16x8* __restrict__ out,
+                                                          int64_t n8) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const f32x4 a = x[2 * i], b = x[2 * i + 1];
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = (__bf16)a[k];
+      o[4 + k] = (__bf16)b[k];
+    }
+    out[i] = o;
+  }
+}
+
+extern "C" int dt_f32_to_bf16(const float* x, void* out, int64_t n, void* stream) {
+  DT_REQUIRE(x && out && n > 0 && (n & 7) == 0, "f32_to_bf16: n must be a multiple of 8");
+  int64_t g = (n / 8 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x,
+                     (bf16x8*)out, n / 8);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

@@ -53,6 +53,7 @@ class UNetEngine:
         self.grad_hook: Optional[Callable[[str, int, int], None]] = None
         # when a list: every dt_conv2d launch appends (kernel name, algorithmic FLOPs, start, end events)
         self.profile: Optional[list] = None
+        self._weights_epoch = 0
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, name: str, numel: int, dtype=torch.float32, device=None) -> torch.Tensor:
@@ -244,21 +245,29 @@ class UNetEngine:
         return logits, (am64 if am64 is not None else am8)
 
     # ------------------------------------------------------------------ bf16 inference leg
-    def _bf16_weights(self, params: torch.Tensor):
-        """bf16 [tap][Cout][Cin] copies of every conv weight except stem and head, repacked when the flat
-        parameter buffer changed (tracked by its version counter)."""
-        key = (params.data_ptr(), params._version)
-        if self._ws.get("bf16_key") == key:
-            return self._ws["bf16_w"]
-        buf = torch.empty(self.spec.n_params, dtype=torch.bfloat16, device=params.device)
+    def _bf16_weights(self, params: torch.Tensor, dgrad: bool = False):
+        """bf16 images of every conv weight except stem and head: [tap][Cout][Cin] for the forward convs, or the
+        data-gradient image (HWIO with reversed taps).  Repacked when the flat parameter buffer changed: torch's
+        version counter catches torch-side writes, ``self.weights_dirty`` the fused optimiser's raw writes."""
+        name = "bf16_wd" if dgrad else "bf16_w"
+        key = (params.data_ptr(), params._version, self._weights_epoch)
+        if self._ws.get(name + "_key") == key:
+            return self._ws[name]
+        buf = self._ws.get(name)
+        if buf is None or buf.device != params.device:
+            buf = torch.empty(self.spec.n_params, dtype=torch.bfloat16, device=params.device)
+        fn = self.lib.dt_pack_dgrad_weights_bf16 if dgrad else self.lib.dt_pack_weights_bf16
         for c in self.spec.convs:
             if c is self.spec.stem or c.bn_key is None:
                 continue
-            _lib.check(self.lib.dt_pack_weights_bf16(_p(params[c.w_off:c.w_off + c.w_size]),
-                                                     _p(buf[c.w_off:c.w_off + c.w_size]), c.k, c.cin, c.cout,
-                                                     _stream()), "dt_pack_weights_bf16")
-        self._ws["bf16_key"], self._ws["bf16_w"] = key, buf
+            _lib.check(fn(_p(params[c.w_off:c.w_off + c.w_size]), _p(buf[c.w_off:c.w_off + c.w_size]), c.k, c.cin,
+                          c.cout, _stream()), "dt_pack_weights_bf16")
+        self._ws[name + "_key"], self._ws[name] = key, buf
         return buf
+
+    def mark_weights_changed(self):
+        """call after writing the flat parameter buffer behind torch's back (fused optimiser step)"""
+        self._weights_epoch += 1
 
     def forward_bf16_eval(self, x_nchw: torch.Tensor, params: torch.Tensor, bnstate: torch.Tensor,
                           want_argmax: Optional[str] = None):
@@ -344,6 +353,255 @@ class UNetEngine:
         _lib.check(lib.dt_head_fwd(_p(d32), _p(params[hd.w_off:hd.w_off + hd.w_size]), _p(params[hd.b_off:hd.b_off + K]),
                                    _p(logits), _p(am64), _p(am8), B, dh, dw, hd.cin, K, st), "dt_head_fwd")
         return logits, (am64 if am64 is not None else am8)
+
+    # ------------------------------------------------------------------ bf16 training (BASELINE configs[2])
+    def forward_bf16_train(self, x_nchw: torch.Tensor, params: torch.Tensor, bnstate: torch.Tensor):
+        """training-mode forward with bf16 activations / weights, fp32 accumulation, fp32 BatchNorm statistics
+        (taken from the accumulators), fp32 master parameters.  Stem and head run in fp32."""
+        sp, lib = self.spec, self.lib
+        B, Cin, H, W = x_nchw.shape
+        if H % 32 or W % 32 or Cin != sp.in_channels:
+            raise RuntimeError(f"bad input {tuple(x_nchw.shape)}")
+        dev, st, bf = x_nchw.device, _stream(), torch.bfloat16
+        wb = self._bf16_weights(params)
+        sv = _Saved()
+        bnws = torch.empty(4 * sp.n_bn_channels, dtype=torch.float32, device=dev)
+        sv.d["bnws"] = bnws
+        nb = sp.n_bn_channels
+
+        def finalize(c, stats, P, count):
+            _lib.check(lib.dt_bn_finalize(_p(stats), P, c.cout, float(count), _p(params[c.g_off:c.g_off + c.cout]),
+                                          _p(params[c.b_off:c.b_off + c.cout]), BN_EPS, BN_MOMENTUM,
+                                          _p(bnstate[2 * c.bn_off:2 * c.bn_off + c.cout]),
+                                          _p(bnstate[2 * c.bn_off + c.cout:2 * c.bn_off + 2 * c.cout]),
+                                          _p(bnws[c.bn_off:c.bn_off + c.cout]),
+                                          _p(bnws[nb + c.bn_off:nb + c.bn_off + c.cout]),
+                                          _p(bnws[2 * nb + c.bn_off:2 * nb + c.bn_off + c.cout]),
+                                          _p(bnws[3 * nb + c.bn_off:3 * nb + c.bn_off + c.cout]), st), "dt_bn_finalize")
+            return self._ss(c, bnws)
+
+        def conv(c, src0, src1, mode0, Hin, Win, in_ss=None):
+            Ho = (Hin + 2 * c.pad - c.k) // c.stride + 1
+            Wo = (Win + 2 * c.pad - c.k) // c.stride + 1
+            C0 = src0.shape[-1]
+            C1 = 0 if src1 is None else src1.shape[-1]
+            desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
+            P = lib.dt_conv2d_bf16_stat_rows(C.byref(desc))
+            if P <= 0:
+                raise RuntimeError(lib.dt_last_error().decode())
+            stats = self._buf("bn_stats", lib.dt_bn_stats_floats(P, c.cout), device=dev)
+            y = torch.empty((B, Ho, Wo, c.cout), dtype=bf, device=dev)
+            _lib.check(lib.dt_conv2d_bf16(C.byref(desc), _p(src0), _p(src1), _p(wb[c.w_off:c.w_off + c.w_size]), _p(y),
+                                          None, _p(stats), _p(in_ss[0]) if in_ss else None,
+                                          _p(in_ss[1]) if in_ss else None, st), "dt_conv2d_bf16")
+            return y, Ho, Wo, finalize(c, stats, P, B * Ho * Wo)
+
+        def bn_act(y, ss, res=None, res_ss=None, y_f32=False):
+            Bq, Hq, Wq, Cq = y.shape
+            z = torch.empty((Bq, Hq, Wq, Cq), dtype=bf, device=dev)
+            _lib.check(lib.dt_bn_act_bf16(_p(y), 1 if y_f32 else 0, _p(ss[0]), _p(ss[1]), _p(res),
+                                          _p(res_ss[0]) if res_ss else None, _p(res_ss[1]) if res_ss else None, _p(z),
+                                          Bq * Hq * Wq, Cq, 1, st), "dt_bn_act_bf16")
+            return z
+
+        x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+        _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw.contiguous()), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
+        y32, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, True)
+        f1 = bn_act(y32, ss, y_f32=True)
+        ystem = torch.empty(y32.shape, dtype=bf, device=dev)
+        _lib.check(lib.dt_f32_to_bf16(_p(y32), _p(ystem), y32.numel(), st), "dt_f32_to_bf16")
+        del y32
+        sv.d["stem"] = dict(x=x, y=ystem, z=f1, Hin=H, Win=W)
+        hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
+        pool = torch.empty((B, hp, wp, 64), dtype=bf, device=dev)
+        amax = torch.empty((B, hp, wp, 64), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dt_maxpool3x3s2_bf16_amax(_p(f1), _p(pool), _p(amax), B, h, w_, 64, st), "dt_maxpool3x3s2_bf16_amax")
+        sv.d["pool"] = dict(amax=amax, H=h, W=w_)
+        feats = [f1]
+        cur, ch, cw = pool, hp, wp
+        for li, blocks in enumerate(sp.layers):
+            for bi, blk in enumerate(blocks):
+                xin = cur
+                y1, h1, w1, ss1 = conv(blk.conv1, xin, None, 0, ch, cw)
+                y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+                if blk.down is not None:
+                    yd, _, _, ssd = conv(blk.down, xin, None, 0, ch, cw)
+                    out = bn_act(y2, ss2, res=yd, res_ss=ssd)
+                else:
+                    yd = None
+                    out = bn_act(y2, ss2, res=xin)
+                sv.d[f"L{li}B{bi}"] = dict(x=xin, y1=y1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
+                cur, ch, cw = out, h2, w2
+            feats.append(cur)
+        d, dh, dw, d_ss = feats[4], ch, cw, None
+        skips = [feats[3], feats[2], feats[1], feats[0], None]
+        for i, blk in enumerate(sp.decoder):
+            y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw, in_ss=d_ss)
+            y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+            if i == len(sp.decoder) - 1:
+                z2 = bn_act(y2, ss2)
+                nxt, nxt_ss = z2, None
+            else:
+                z2 = None
+                nxt, nxt_ss = y2, ss2
+            sv.d[f"D{i}"] = dict(x=d, x_virtual=d_ss is not None, skip=skips[i], y1=y1, y2=y2, z2=z2, H=h1, W=w1)
+            d, dh, dw, d_ss = nxt, h2, w2, nxt_ss
+        hd = sp.head
+        K = hd.cout
+        d32 = torch.empty((B, dh, dw, hd.cin), dtype=torch.float32, device=dev)
+        _lib.check(lib.dt_bf16_to_f32(_p(d), _p(d32), d.numel(), st), "dt_bf16_to_f32")
+        logits = torch.empty((B, K, dh, dw), dtype=torch.float32, device=dev)
+        _lib.check(lib.dt_head_fwd(_p(d32), _p(params[hd.w_off:hd.w_off + hd.w_size]), _p(params[hd.b_off:hd.b_off + K]),
+                                   _p(logits), None, None, B, dh, dw, hd.cin, K, st), "dt_head_fwd")
+        sv.d["head"] = dict(x=d32, H=dh, W=dw)
+        sv.d["B"] = B
+        sv.d["bf16"] = True
+        self.saved = sv
+        return logits
+
+    def backward_bf16(self, dlogits: torch.Tensor, params: torch.Tensor, grads: torch.Tensor):
+        """reverse pass of forward_bf16_train: bf16 activation gradients, fp32 parameter gradients"""
+        sp, lib = self.spec, self.lib
+        S = self.saved.d
+        B, bnws = S["B"], S["bnws"]
+        dev, st, bf = dlogits.device, _stream(), torch.bfloat16
+        wbd = self._bf16_weights(params, dgrad=True)
+        nb = sp.n_bn_channels
+
+        def bn_bwd(c, dout, out_act, y, dres=None, dres_acc=False, virtual_act=False):
+            Bq, Hq, Wq, Cq = y.shape
+            n_pix = Bq * Hq * Wq
+            P = lib.dt_bn_bwd_rows_bf16(n_pix)
+            red = self._buf("bn_red", lib.dt_bn_stats_floats(P, Cq), device=dev)
+            mean = bnws[c.bn_off:c.bn_off + Cq]
+            invstd = bnws[nb + c.bn_off:nb + c.bn_off + Cq]
+            asc, ash = self._ss(c, bnws) if virtual_act else (None, None)
+            _lib.check(lib.dt_bn_bwd_reduce_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc), _p(ash),
+                                                 _p(red), n_pix, Cq, st), "dt_bn_bwd_reduce_bf16")
+            dy = torch.empty(y.shape, dtype=bf, device=dev)
+            _lib.check(lib.dt_bn_bwd_apply_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd),
+                                                _p(params[c.g_off:c.g_off + Cq]), _p(asc), _p(ash), _p(red), P,
+                                                _p(grads[c.g_off:c.g_off + Cq]), _p(grads[c.b_off:c.b_off + Cq]),
+                                                _p(dy), _p(dres), 1 if dres_acc else 0, n_pix, Cq, st),
+                       "dt_bn_bwd_apply_bf16")
+            return dy
+
+        def wgrad(c, src0, src1, mode0, Hin, Win, dy, in_ss=None):
+            Ho, Wo = dy.shape[1], dy.shape[2]
+            C0 = src0.shape[-1]
+            C1 = 0 if src1 is None else src1.shape[-1]
+            desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
+            nbytes = lib.dt_conv2d_wgrad_bf16_workspace(C.byref(desc))
+            if nbytes == 0:
+                raise RuntimeError(lib.dt_last_error().decode())
+            ws = self._buf("wgrad_ws", nbytes // 4, device=dev)
+            _lib.check(lib.dt_conv2d_wgrad_bf16(C.byref(desc), _p(src0), _p(src1), _p(dy),
+                                                _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
+                                                _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None, st),
+                       "dt_conv2d_wgrad_bf16")
+
+        def dgrad(c, dy, Hin, Win, out0, out1=None, split=0, acc=False):
+            Ho, Wo = dy.shape[1], dy.shape[2]
+            pad = c.k - 1 - c.pad
+            if c.stride == 1:
+                desc = self._desc(B, Ho, Wo, c.cout, 0, 0, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
+            else:
+                desc = self._desc(B, Hin, Win, c.cout, 0, 2, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
+            _lib.check(lib.dt_conv2d_bf16(C.byref(desc), _p(dy), None, _p(wbd[c.w_off:c.w_off + c.w_size]), _p(out0),
+                                          _p(out1), None, None, None, st), "dt_conv2d_bf16(dgrad)")
+
+        # ---- head (fp32) -> bf16 gradient of the last decoder activation
+        hd, hsv = sp.head, S["head"]
+        H, W, K = hsv["H"], hsv["W"], sp.head.cout
+        g32 = torch.empty_like(hsv["x"])
+        P = lib.dt_head_bwd_rows(B, H, W)
+        red = self._buf("head_red", lib.dt_head_bwd_red_floats(B, H, W, hd.cin, K), device=dev)
+        _lib.check(lib.dt_head_bwd(_p(hsv["x"]), _p(params[hd.w_off:hd.w_off + hd.w_size]), _p(dlogits.contiguous()),
+                                   _p(g32), _p(red), B, H, W, hd.cin, K, st), "dt_head_bwd")
+        _lib.check(lib.dt_head_bwd_finalize(_p(red), P, _p(grads[hd.w_off:hd.w_off + hd.w_size]),
+                                            _p(grads[hd.b_off:hd.b_off + K]), hd.cin, K, st), "dt_head_bwd_finalize")
+        g = torch.empty(g32.shape, dtype=bf, device=dev)
+        _lib.check(lib.dt_f32_to_bf16(_p(g32), _p(g), g32.numel(), st), "dt_f32_to_bf16")
+        del g32
+
+        skip_grads = [None] * 5
+        for i in range(4, -1, -1):
+            blk, d = sp.decoder[i], S[f"D{i}"]
+            Hh, Ww = d["H"], d["W"]
+            dy2 = bn_bwd(blk.conv2, g, d["z2"], d["y2"], virtual_act=d["z2"] is None)
+            wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+            dz1 = torch.empty(d["y1"].shape, dtype=bf, device=dev)
+            dgrad(blk.conv2, dy2, Hh, Ww, dz1)
+            del dy2
+            dy1 = bn_bwd(blk.conv1, dz1, None, d["y1"], virtual_act=True)
+            del dz1
+            x_ss = self._ss(sp.decoder[i - 1].conv2, bnws) if d["x_virtual"] else None
+            wgrad(blk.conv1, d["x"], d["skip"], 1, Hh, Ww, dy1, in_ss=x_ss)
+            cx = blk.in_ch
+            dup = torch.empty((B, Hh, Ww, cx), dtype=bf, device=dev)
+            if d["skip"] is not None:
+                dskip = torch.empty(d["skip"].shape, dtype=bf, device=dev)
+                dgrad(blk.conv1, dy1, Hh, Ww, dup, dskip, split=cx)
+                skip_grads[3 - i] = dskip
+            else:
+                dgrad(blk.conv1, dy1, Hh, Ww, dup)
+            del dy1
+            g = torch.empty(d["x"].shape, dtype=bf, device=dev)
+            _lib.check(lib.dt_upsample2x_bwd_bf16(_p(dup), _p(g), B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd_bf16")
+            del dup
+            S[f"D{i}"] = None
+        if self.grad_hook:
+            self.grad_hook(*sp.buckets[0])
+
+        for li in (3, 2, 1, 0):
+            blocks = sp.layers[li]
+            for bi in range(len(blocks) - 1, -1, -1):
+                blk, r = blocks[bi], S[f"L{li}B{bi}"]
+                Hin, Win, Hh, Ww = r["Hin"], r["Win"], r["H"], r["W"]
+                gin, gin_has = None, False
+                if bi == 0 and li > 0 and skip_grads[li] is not None:
+                    gin, gin_has = skip_grads[li], True
+                if gin is None:
+                    gin = torch.empty(r["x"].shape, dtype=bf, device=dev)
+                if blk.down is None:
+                    dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gin, dres_acc=gin_has)
+                    gin_has = True
+                    dyd = None
+                else:
+                    gd = torch.empty(r["out"].shape, dtype=bf, device=dev)
+                    dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gd)
+                    dyd = bn_bwd(blk.down, gd, None, r["yd"])
+                    del gd
+                wgrad(blk.conv2, r["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+                dz1 = torch.empty(r["y1"].shape, dtype=bf, device=dev)
+                dgrad(blk.conv2, dy2, Hh, Ww, dz1)
+                del dy2
+                dy1 = bn_bwd(blk.conv1, dz1, None, r["y1"], virtual_act=True)
+                del dz1
+                wgrad(blk.conv1, r["x"], None, 0, Hin, Win, dy1)
+                dgrad(blk.conv1, dy1, Hin, Win, gin, acc=gin_has)
+                gin_has = True
+                del dy1
+                if dyd is not None:
+                    wgrad(blk.down, r["x"], None, 0, Hin, Win, dyd)
+                    dgrad(blk.down, dyd, Hin, Win, gin, acc=True)
+                    del dyd
+                g = gin
+                S[f"L{li}B{bi}"] = None
+            if li > 0 and self.grad_hook:
+                self.grad_hook(*sp.buckets[4 - li])
+
+        pl, stem = S["pool"], S["stem"]
+        gf1 = skip_grads[0]
+        _lib.check(lib.dt_maxpool3x3s2_bwd_bf16(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
+                   "dt_maxpool3x3s2_bwd_bf16")
+        dy = bn_bwd(sp.stem, gf1, stem["z"], stem["y"])
+        dy32 = torch.empty(dy.shape, dtype=torch.float32, device=dev)
+        _lib.check(lib.dt_bf16_to_f32(_p(dy), _p(dy32), dy.numel(), st), "dt_bf16_to_f32")
+        self._wgrad(sp.stem, grads, stem["x"], None, 0, B, stem["Hin"], stem["Win"], dy32)
+        if self.grad_hook:
+            self.grad_hook(*sp.buckets[4])
+        self.saved = None
 
     # ------------------------------------------------------------------ backward units
     def _bn_bwd(self, c: ConvSpec, params, grads, bnws, dout, out_act, y, dres=None, dres_acc=False,
@@ -518,7 +776,10 @@ class UNetEngine:
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, flat, module):
-        logits, _ = module.engine.forward(x, flat.detach(), module.bn_state, module.training, save=True)
+        if module.precision == "bf16" and module.training:
+            logits = module.engine.forward_bf16_train(x, flat.detach(), module.bn_state)
+        else:
+            logits, _ = module.engine.forward(x, flat.detach(), module.bn_state, module.training, save=True)
         ctx.module = module
         module._bn_tracked_inc()
         return logits
@@ -527,7 +788,10 @@ class _UNetFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         m = ctx.module
         grads = m._grad_buffer()
-        m.engine.backward(dlogits, m.flat_params.detach(), grads)
+        if m.engine.saved is not None and m.engine.saved.d.get("bf16"):
+            m.engine.backward_bf16(dlogits, m.flat_params.detach(), grads)
+        else:
+            m.engine.backward(dlogits, m.flat_params.detach(), grads)
         # a trainer that consumes the flat buffer directly (HipTrainer) opts out of autograd's copy into .grad
         return None, (grads if m.deliver_grad_to_autograd else None), None
 
@@ -554,6 +818,9 @@ class UNetHIP(nn.Module):
         self._engine: Optional[UNetEngine] = None
         self._grads: Optional[torch.Tensor] = None
         self.deliver_grad_to_autograd = True
+        # "fp32" (BASELINE configs[1]) or "bf16": bf16 activations/weights, fp32 accumulation, fp32 master
+        # parameters and optimiser (configs[2]; the AMP setting of the reference's protocol.md:27)
+        self.precision = "fp32"
         self.reset_parameters()
 
     # ------------------------------------------------------------------ init / state_dict
@@ -620,6 +887,8 @@ class UNetHIP(nn.Module):
         if strict and missing:
             raise RuntimeError(f"missing keys in state_dict: {missing[:8]}{'...' if len(missing) > 8 else ''}")
         self.flat_params.data.copy_(flat.to(self.flat_params.device))
+        if self._engine is not None:
+            self._engine.mark_weights_changed()
         self.bn_state.copy_(bn.to(self.bn_state.device))
         self.num_batches_tracked.copy_(nbt.to(self.num_batches_tracked.device))
         return missing

@@ -47,11 +47,15 @@ class GradReducer:
 
 class HipTrainer:
     def __init__(self, model: UNetHIP, lr: float = 3e-4, clip: float = 0.5,
-                 losses: Sequence[str] = ("GDICE", "FOCAL"), distributed: bool = False, group=None):
+                 losses: Sequence[str] = ("GDICE", "FOCAL"), distributed: bool = False, group=None,
+                 precision: str = "fp32"):
         if not model.flat_params.is_cuda:
             raise RuntimeError("HipTrainer needs the model on an MI355X (model.to('cuda'))")
         self.model = model
         model.deliver_grad_to_autograd = False   # this trainer reads the engine's flat gradient buffer itself
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision {precision!r}: use 'fp32' or 'bf16'")
+        model.precision = precision
         self.losses = tuple(losses)
         self.opt = FlatAdam(model.flat_params.data, lr=lr, max_norm=clip)
         self.reducer = GradReducer(group) if distributed else None
@@ -81,6 +85,7 @@ class HipTrainer:
         # non-finite loss -> skip the update (reference segmodel.py:220-222 returns None)
         skip = (~torch.isfinite(loss.detach())).to(torch.int32).reshape(1)
         norm = self.opt.step(m._grad_buffer(), grad_scale=1.0 / self.world, skip_flag=skip)
+        m.engine.mark_weights_changed()   # the fused optimiser wrote the flat buffer behind torch's version counter
         m.flat_params.grad = None
         self.last = {"loss": loss.detach(), "parts": parts, "grad_norm": norm, "label_error": err, "skipped": skip}
         return loss.detach()

@@ -196,6 +196,21 @@ int dt_bn_act_bf16(const void* y, int y_is_f32, const float* scale, const float*
                    const float* rscale, const float* rshift, void* out, int64_t n_pix, int C, int relu, void* stream);
 int dt_maxpool3x3s2_bf16(const void* x, void* out, int B, int H, int W, int C, void* stream);
 int dt_bf16_to_f32(const void* x, float* out, int64_t n, void* stream);
+int dt_f32_to_bf16(const float* x, void* out, int64_t n, void* stream);
+/* bf16 training passes: same contracts as their fp32 namesakes, tensors bf16, sums fp32/fp64.  `red` holds
+ * dt_bn_stats_floats(dt_bn_bwd_rows_bf16(n_pix), C) floats. */
+int dt_bn_bwd_rows_bf16(int64_t n_pix);
+int dt_bn_bwd_reduce_bf16(const void* dout, const void* out_act, const void* y, const float* mean,
+                          const float* invstd, const float* act_scale, const float* act_shift, float* red,
+                          int64_t n_pix, int C, void* stream);
+int dt_bn_bwd_apply_bf16(const void* dout, const void* out_act, const void* y, const float* mean, const float* invstd,
+                         const float* gamma, const float* act_scale, const float* act_shift, float* red, int P,
+                         float* dgamma, float* dbeta, void* dy, void* dres, int dres_accumulate, int64_t n_pix, int C,
+                         void* stream);
+int dt_maxpool3x3s2_bf16_amax(const void* x, void* out, uint8_t* argmax, int B, int H, int W, int C, void* stream);
+int dt_maxpool3x3s2_bwd_bf16(const void* dout, const uint8_t* argmax, void* dx, int accumulate, int B, int H, int W,
+                             int C, void* stream);
+int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------ optimiser (K22) */
 /* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
