@@ -314,6 +314,12 @@ static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_) {
   *tn_ = tn;
 }
 
+extern "C" int dt_conv2d_bf16_config(const dt_conv_desc* d, int* tw, int* tn) {
+  if (bf_validate(d) != DT_OK) return DT_EINVAL;
+  bf_cfg(d, tw, tn);
+  return DT_OK;
+}
+
 extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
   if (bf_validate(d) != DT_OK) return DT_EINVAL;
   int tw, tn;

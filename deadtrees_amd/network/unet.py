@@ -265,6 +265,30 @@ class UNetEngine:
         self._ws[name + "_key"], self._ws[name] = key, buf
         return buf
 
+    def _conv_bf16(self, desc, src0, src1, w, out0, out1, stats, in_ss, what="dt_conv2d_bf16"):
+        prof = self.profile
+        if prof is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(self.lib.dt_conv2d_bf16(C.byref(desc), _p(src0), _p(src1), _p(w), _p(out0), _p(out1), _p(stats),
+                                           _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
+                                           _stream()), what)
+        if prof is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            tw, tn = C.c_int(), C.c_int()
+            self.lib.dt_conv2d_bf16_config(C.byref(desc), C.byref(tw), C.byref(tn))
+            flops = 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout * desc.Ho * desc.Wo * desc.B
+            if desc.mode0 == 2:
+                flops /= 4.0
+            sdiv = 4 if desc.mode0 else 1
+            nbytes = 2.0 * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
+                                     desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
+                2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
+            name = (f"conv_fwd_bf16_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, "
+                    f"{'true' if in_ss else 'false'}>")
+            prof.append((name, flops, e0, e1, nbytes))
+
     def mark_weights_changed(self):
         """call after writing the flat parameter buffer behind torch's back (fused optimiser step)"""
         self._weights_epoch += 1
@@ -299,9 +323,7 @@ class UNetEngine:
             C1 = 0 if src1 is None else src1.shape[-1]
             desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
             y = torch.empty((B, Ho, Wo, c.cout), dtype=bf, device=dev)
-            _lib.check(lib.dt_conv2d_bf16(C.byref(desc), _p(src0), _p(src1), _p(wb[c.w_off:c.w_off + c.w_size]), _p(y),
-                                          None, None, _p(in_ss[0]) if in_ss else None,
-                                          _p(in_ss[1]) if in_ss else None, st), "dt_conv2d_bf16")
+            self._conv_bf16(desc, src0, src1, wb[c.w_off:c.w_off + c.w_size], y, None, None, in_ss)
             return y, Ho, Wo, affine(c)
 
         def bn_act(y, ss, res=None, res_ss=None, y_f32=False):
@@ -391,9 +413,7 @@ class UNetEngine:
                 raise RuntimeError(lib.dt_last_error().decode())
             stats = self._buf("bn_stats", lib.dt_bn_stats_floats(P, c.cout), device=dev)
             y = torch.empty((B, Ho, Wo, c.cout), dtype=bf, device=dev)
-            _lib.check(lib.dt_conv2d_bf16(C.byref(desc), _p(src0), _p(src1), _p(wb[c.w_off:c.w_off + c.w_size]), _p(y),
-                                          None, _p(stats), _p(in_ss[0]) if in_ss else None,
-                                          _p(in_ss[1]) if in_ss else None, st), "dt_conv2d_bf16")
+            self._conv_bf16(desc, src0, src1, wb[c.w_off:c.w_off + c.w_size], y, None, stats, in_ss)
             return y, Ho, Wo, finalize(c, stats, P, B * Ho * Wo)
 
         def bn_act(y, ss, res=None, res_ss=None, y_f32=False):
@@ -507,8 +527,8 @@ class UNetEngine:
                 desc = self._desc(B, Ho, Wo, c.cout, 0, 0, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
             else:
                 desc = self._desc(B, Hin, Win, c.cout, 0, 2, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
-            _lib.check(lib.dt_conv2d_bf16(C.byref(desc), _p(dy), None, _p(wbd[c.w_off:c.w_off + c.w_size]), _p(out0),
-                                          _p(out1), None, None, None, st), "dt_conv2d_bf16(dgrad)")
+            self._conv_bf16(desc, dy, None, wbd[c.w_off:c.w_off + c.w_size], out0, out1, None, None,
+                            "dt_conv2d_bf16(dgrad)")
 
         # ---- head (fp32) -> bf16 gradient of the last decoder activation
         hd, hsv = sp.head, S["head"]
