@@ -54,6 +54,9 @@ class UNetEngine:
         # when a list: every dt_conv2d launch appends (kernel name, algorithmic FLOPs, start, end events)
         self.profile: Optional[list] = None
         self._weights_epoch = 0
+        # side-stream weight gradients: measured SLOWER on MI355X (485 vs 528 tiles/s fp32, 1505 vs 1566 bf16): the
+        # co-resident wgrad / dgrad workgroups halve each other's occupancy and share the matrix pipe — off by default
+        self.overlap_wgrad = False
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, name: str, numel: int, dtype=torch.float32, device=None) -> torch.Tensor:
@@ -289,6 +292,38 @@ class UNetEngine:
                     f"{'true' if in_ss else 'false'}>")
             prof.append((name, flops, e0, e1, nbytes))
 
+    # ---- weight gradients run on a side stream, concurrently with the data-gradient chain of the main stream:
+    # both only depend on dy, and the many tiny reduction / finalize launches of either chain otherwise leave
+    # the chip idle.  Ordering: side waits for the event recorded after dy was produced; main waits for the side
+    # stream before a gradient bucket is handed to the reducer / optimiser.  Tensors touched by the side stream are
+    # registered with the caching allocator (record_stream) so they are not recycled while still in use.
+    def _side_stream(self, device):
+        st = self._ws.get("side_stream")
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._ws["side_stream"] = st
+        return st
+
+    def _on_side(self, fn, *tensors):
+        main = torch.cuda.current_stream()
+        side = self._side_stream(main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            fn()
+
+    def _join_side(self):
+        main = torch.cuda.current_stream()
+        side = self._ws.get("side_stream")
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            main.wait_event(ev)
+
     def mark_weights_changed(self):
         """call after writing the flat parameter buffer behind torch's back (fused optimiser step)"""
         self._weights_epoch += 1
@@ -506,7 +541,10 @@ class UNetEngine:
                        "dt_bn_bwd_apply_bf16")
             return dy
 
-        def wgrad(c, src0, src1, mode0, Hin, Win, dy, in_ss=None):
+        def wgrad(c, src0, src1, mode0, Hin, Win, dy, in_ss=None, side=True):
+            if side and self.overlap_wgrad:
+                self._on_side(lambda: wgrad(c, src0, src1, mode0, Hin, Win, dy, in_ss, side=False), src0, src1, dy)
+                return
             Ho, Wo = dy.shape[1], dy.shape[2]
             C0 = src0.shape[-1]
             C1 = 0 if src1 is None else src1.shape[-1]
@@ -517,8 +555,8 @@ class UNetEngine:
             ws = self._buf("wgrad_ws", nbytes // 4, device=dev)
             _lib.check(lib.dt_conv2d_wgrad_bf16(C.byref(desc), _p(src0), _p(src1), _p(dy),
                                                 _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
-                                                _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None, st),
-                       "dt_conv2d_wgrad_bf16")
+                                                _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
+                                                _stream()), "dt_conv2d_wgrad_bf16")
 
         def dgrad(c, dy, Hin, Win, out0, out1=None, split=0, acc=False):
             Ho, Wo = dy.shape[1], dy.shape[2]
@@ -571,6 +609,7 @@ class UNetEngine:
             del dup
             S[f"D{i}"] = None
         if self.grad_hook:
+            self._join_side()
             self.grad_hook(*sp.buckets[0])
 
         for li in (3, 2, 1, 0):
@@ -609,6 +648,7 @@ class UNetEngine:
                 g = gin
                 S[f"L{li}B{bi}"] = None
             if li > 0 and self.grad_hook:
+                self._join_side()
                 self.grad_hook(*sp.buckets[4 - li])
 
         pl, stem = S["pool"], S["stem"]
@@ -619,6 +659,7 @@ class UNetEngine:
         dy32 = torch.empty(dy.shape, dtype=torch.float32, device=dev)
         _lib.check(lib.dt_bf16_to_f32(_p(dy), _p(dy32), dy.numel(), st), "dt_bf16_to_f32")
         self._wgrad(sp.stem, grads, stem["x"], None, 0, B, stem["Hin"], stem["Win"], dy32)
+        self._join_side()
         if self.grad_hook:
             self.grad_hook(*sp.buckets[4])
         self.saved = None
@@ -647,7 +688,11 @@ class UNetEngine:
                    "dt_bn_bwd_apply")
         return dy
 
-    def _wgrad(self, c: ConvSpec, grads, src0, src1, mode0, B, Hin, Win, dy, in_ss=None):
+    def _wgrad(self, c: ConvSpec, grads, src0, src1, mode0, B, Hin, Win, dy, in_ss=None, side=True):
+        if side and self.overlap_wgrad:
+            self._on_side(lambda: self._wgrad(c, grads, src0, src1, mode0, B, Hin, Win, dy, in_ss, side=False),
+                          src0, src1, dy)
+            return
         Ho, Wo = dy.shape[1], dy.shape[2]
         C0 = src0.shape[-1]
         C1 = 0 if src1 is None else src1.shape[-1]
@@ -735,6 +780,7 @@ class UNetEngine:
             del dup
             S[f"D{i}"] = None
         if self.grad_hook:
+            self._join_side()
             self.grad_hook(*sp.buckets[0])
 
         # g = gradient wrt f5 ; encoder layers in reverse
@@ -778,6 +824,7 @@ class UNetEngine:
                 g = gin
                 S[f"L{li}B{bi}"] = None
             if li > 0 and self.grad_hook:
+                self._join_side()
                 self.grad_hook(*sp.buckets[4 - li])
 
         # ---- maxpool + stem
@@ -788,6 +835,7 @@ class UNetEngine:
                    "dt_maxpool3x3s2_bwd")
         dy = self._bn_bwd(sp.stem, params, grads, bnws, gf1, stem["z"], stem["y"])
         self._wgrad(sp.stem, grads, stem["x"], None, 0, B, stem["Hin"], stem["Win"], dy)
+        self._join_side()
         if self.grad_hook:
             self.grad_hook(*sp.buckets[4])
         self.saved = None
