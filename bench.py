@@ -23,8 +23,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_TILE_TRAIN = 186.53e9      # SURVEY §8d / BASELINE.md §2 (conv FLOPs fwd+bwd, 512x512x3, K=2)
-BYTES_PER_TILE_TRAIN = 924.3e6      # ideal-fused fp32 algorithmic HBM bytes per tile
+FLOP_PER_TILE_TRAIN = 186.53e9      # SURVEY §8d / BASELINE.md §2 (conv FLOPs fwd+bwd, 512x512x3, K=2); scaled by
+BYTES_PER_TILE_TRAIN = 924.3e6      # (size/512)^2 for other tile sizes.  ideal-fused fp32 algorithmic HBM bytes
 PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
@@ -143,11 +143,11 @@ def main():
                 roof["traffic"] = json.load(open(tfile)).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
-    per_gpu_tiles_s = B * args.steps / wall
+    per_gpu_tiles_s = B * args.steps / wall * (S / 512.0) ** 2   # 512x512-equivalent tiles for the FLOP/byte model
     peak_tf = PEAK_FP32_TFLOPS if args.precision == "fp32" else 2500.0   # dense bf16 MFMA peak
     bytes_per_tile = BYTES_PER_TILE_TRAIN if args.precision == "fp32" else 462.2e6
     out = {
-        "metric": "512x512 RGB tiles/sec (train fwd+bwd)", "value": round(value, 2), "unit": "tiles/s",
+        "metric": f"{S}x{S} RGB tiles/sec (train fwd+bwd)", "value": round(value, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "bf16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
