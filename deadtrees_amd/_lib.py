@@ -74,6 +74,10 @@ SIGNATURES = {
     "dt_pack_weights_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_bn_act_bf16": (C.c_int, [c_f, C.c_int, c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, C.c_int, c_f]),
     "dt_maxpool3x3s2_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_conv2d_out_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f]),
+    "dt_conv2d_wgrad_stem_dy_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, SZ, c_f]),
+    "dt_head_fwd_bf16": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_head_bwd_bf16": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_bf16_to_f32": (C.c_int, [c_f, c_f, I64, c_f]),
     "dt_f32_to_bf16": (C.c_int, [c_f, c_f, I64, c_f]),
     "dt_bn_bwd_rows_bf16": (C.c_int, [I64]),

@@ -25,6 +25,7 @@ struct ConvArgs {
   const float* in_scale;  // optional per-channel affine + ReLU applied to source 0 while staging (fused BatchNorm
   const float* in_shift;  // apply of the producer layer: z = relu(y*scale+shift) is never materialised)
   float* out0;
+  __bf16* out0_bf16;      // when set (bf16 training path, stem): out0 is written as bf16 instead (no split/accumulate)
   float* out1;
   float* stats;
   int B, Hin, Win, C0, C1, mode0;
@@ -485,7 +486,10 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
             const float v = acc[mt][j][i];
             s1[j] += v;
             s2[j] += v * v;
-            outp[off[i]] = v;
+            if (a.out0_bf16 != nullptr)
+              a.out0_bf16[off[i]] = (__bf16)v;
+            else
+              outp[off[i]] = v;
           }
       }
     }
@@ -590,9 +594,19 @@ static int launch_tw_tn(const ConvArgs& a, const ConvCfg& c, hipStream_t st) {
   return launch<KS, STRIDE, 8, 32, CK>(a, st);
 }
 
+static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* w, float* out0,
+                       float* out1, float* stats, const float* in_scale, const float* in_shift, void* out_bf16,
+                       void* stream);
+
 extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const float* w,
                          float* out0, float* out1, float* stats, const float* in_scale, const float* in_shift,
                          void* stream) {
+  return conv2d_impl(d, src0, src1, w, out0, out1, stats, in_scale, in_shift, nullptr, stream);
+}
+
+static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* w, float* out0,
+                       float* out1, float* stats, const float* in_scale, const float* in_shift, void* out_bf16,
+                       void* stream) {
   int rc = validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && w && out0, "conv: null pointer");
@@ -606,7 +620,7 @@ extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* 
   ConvCfg c = pick_cfg(d);
   ConvArgs a;
   a.src0 = src0; a.src1 = src1; a.w = w; a.out0 = out0; a.out1 = out1; a.stats = stats;
-  a.in_scale = in_scale; a.in_shift = in_shift;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.out0_bf16 = (__bf16*)out_bf16;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.cout_split = d->cout_split; a.pad = d->pad;
   a.accumulate = d->accumulate;
@@ -664,6 +678,15 @@ extern "C" int dt_weight_flip_transpose(const float* w, float* wd, int ksize, in
 }
 
 // which kernel instantiation dt_conv2d launches for a descriptor (profiling / roofline attribution)
+// fp32 operands and accumulation, bf16 output (+ fp32 BatchNorm partial statistics): the stem of the bf16 path
+extern "C" int dt_conv2d_out_bf16(const dt_conv_desc* d, const float* src0, const float* w_hwio, void* out_bf16,
+                                  float* stats, void* stream) {
+  DT_REQUIRE(d && d->cout_split == 0 && d->accumulate == 0 && d->C1 == 0 && out_bf16, "conv_out_bf16: bad args");
+  DT_REQUIRE(!dt_conv2d_n16_supported(d), "conv_out_bf16: not built for the 16-wide kernels");
+  return conv2d_impl(d, src0, nullptr, w_hwio, reinterpret_cast<float*>(out_bf16), nullptr, stats, nullptr, nullptr,
+                     out_bf16, stream);
+}
+
 // 1 when dt_conv2d runs the parity-class (zero-insertion) tiles for this descriptor
 extern "C" int dt_conv2d_uses_zi(const dt_conv_desc* d) {
   if (validate(d) != DT_OK) return 0;

@@ -17,6 +17,7 @@ struct WgradArgs {
   const float* in_scale;  // optional fused BatchNorm-apply + ReLU on source 0 (see conv_fwd.hip)
   const float* in_shift;
   const float* dy;
+  const __bf16* dy_bf16;  // stem only: dy given in bf16 (bf16 training path)
   float* ws;  // [parts][taps][Cin][Cout]
   int B, Hin, Win, C0, C1, mode0;
   int Ho, Wo, Cout, pad;
@@ -259,8 +260,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_stem_kernel(const WgradArgs
       const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
       const int c = co0 + 4 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < YT && oy < a.Ho && ox < a.Wo && c < a.Cout)
-        v = *reinterpret_cast<const f32x4*>(a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + c);
+      if (idx < YT && oy < a.Ho && ox < a.Wo && c < a.Cout) {
+        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + c;
+        if (a.dy_bf16 != nullptr) {
+          typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+          const bf16x4_t q = *reinterpret_cast<const bf16x4_t*>(a.dy_bf16 + o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = (float)q[k];
+        } else {
+          v = *reinterpret_cast<const f32x4*>(a.dy + o);
+        }
+      }
       ry[it] = v;
     }
     __syncthreads();
@@ -408,9 +418,27 @@ static int wg_dispatch(const WgradArgs& a, const WgCfg& c, int grid, hipStream_t
   return wg_launch<KS, STRIDE, TW, 128, 1, 1>(a, grid, st);
 }
 
+static int wgrad_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy, const void* dy_bf16,
+                      float* dw, float* workspace, size_t workspace_bytes, const float* in_scale,
+                      const float* in_shift, void* stream);
+
 extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy,
                                float* dw, float* workspace, size_t workspace_bytes, const float* in_scale,
                                const float* in_shift, void* stream) {
+  return wgrad_impl(d, src0, src1, dy, nullptr, dw, workspace, workspace_bytes, in_scale, in_shift, stream);
+}
+
+// stem (7x7/2, fp32 image) weight gradient with dy in bf16 — the bf16 training path
+extern "C" int dt_conv2d_wgrad_stem_dy_bf16(const dt_conv_desc* d, const float* src0, const void* dy_bf16, float* dw,
+                                            float* workspace, size_t workspace_bytes, void* stream) {
+  DT_REQUIRE(d && d->ksize == 7 && dy_bf16, "wgrad_stem_dy_bf16: 7x7 stem only");
+  return wgrad_impl(d, src0, nullptr, reinterpret_cast<const float*>(dy_bf16), dy_bf16, dw, workspace, workspace_bytes,
+                    nullptr, nullptr, stream);
+}
+
+static int wgrad_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy, const void* dy_bf16,
+                      float* dw, float* workspace, size_t workspace_bytes, const float* in_scale,
+                      const float* in_shift, void* stream) {
   int rc = wg_validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && dy && dw && workspace, "wgrad: null pointer");
@@ -425,6 +453,7 @@ extern "C" int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const f
   DT_REQUIRE(in_scale == nullptr || (d->ksize == 3 && d->stride == 1 && d->mode0 != 2),
              "wgrad: input transform needs a 3x3 stride-1 layer without zero-insertion");
   a.src0 = src0; a.src1 = src1; a.dy = dy; a.ws = workspace; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.dy_bf16 = (const __bf16*)dy_bf16;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.pad = d->pad;
   a.tiles_x = c.tiles_x; a.tiles_y = c.tiles_y; a.T = c.T;

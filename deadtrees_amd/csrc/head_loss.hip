@@ -21,8 +21,21 @@
 #define HEAD_CIN 16
 
 // ------------------------------------------------------------------ head forward
-template <int K>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive channels of pixel `pix_elem_off` from an fp32 or bf16 NHWC tensor
+template <bool XB>
+__device__ __forceinline__ f32x4 head_load4(const void* x, size_t elem_off) {
+  if constexpr (XB) {
+    const hbf16x4 q = *reinterpret_cast<const hbf16x4*>(reinterpret_cast<const __bf16*>(x) + elem_off);
+    return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+  } else {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + elem_off);
+  }
+}
+
+template <int K, bool XB = false>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ logits,
                                                        int64_t* __restrict__ am64, uint8_t* __restrict__ am8, int B,
                                                        int H, int W) {
@@ -41,7 +54,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-      v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + 4 * q);
+      v = head_load4<XB>(x, (((size_t)b * H + iy) * W + ix) * C + 4 * q);
 #pragma unroll
     for (int k = 0; k < 4; ++k) tile[pix][4 * q + k] = v[k];
   }
@@ -82,21 +95,32 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   }
 }
 
-extern "C" int dt_head_fwd(const float* x, const float* w, const float* bias, float* logits, int64_t* am64,
-                           uint8_t* am8, int B, int H, int W, int Cin, int K, void* stream) {
+template <bool XB>
+static int head_fwd_launch(const void* x, const float* w, const float* bias, float* logits, int64_t* am64, uint8_t* am8,
+                           int B, int H, int W, int Cin, int K, void* stream) {
   DT_REQUIRE(x && w && bias && logits && B > 0 && H > 0 && W > 0, "head_fwd: bad args");
   DT_REQUIRE(Cin == HEAD_CIN, "head_fwd: Cin must be %d (decoder_channels[-1])", HEAD_CIN);
   DT_REQUIRE(K >= 1 && K <= HEAD_MAXK, "head_fwd: K=%d unsupported (1..%d)", K, HEAD_MAXK);
   const int grid = B * dt_cdiv(H, HEAD_TH) * dt_cdiv(W, HEAD_TW);
   hipStream_t st = (hipStream_t)stream;
   switch (K) {
-    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
-    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
-    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
-    default: hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+    case 1: hipLaunchKernelGGL((head_fwd_kernel<1, XB>), dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+    case 2: hipLaunchKernelGGL((head_fwd_kernel<2, XB>), dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+    case 3: hipLaunchKernelGGL((head_fwd_kernel<3, XB>), dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
+    default: hipLaunchKernelGGL((head_fwd_kernel<4, XB>), dim3(grid), dim3(256), 0, st, x, w, bias, logits, am64, am8, B, H, W); break;
   }
   DT_LAUNCH_CHECK();
   return DT_OK;
+}
+
+extern "C" int dt_head_fwd(const float* x, const float* w, const float* bias, float* logits, int64_t* am64,
+                           uint8_t* am8, int B, int H, int W, int Cin, int K, void* stream) {
+  return head_fwd_launch<false>(x, w, bias, logits, am64, am8, B, H, W, Cin, K, stream);
+}
+
+extern "C" int dt_head_fwd_bf16(const void* x_bf16, const float* w, const float* bias, float* logits, int64_t* am64,
+                                uint8_t* am8, int B, int H, int W, int Cin, int K, void* stream) {
+  return head_fwd_launch<true>(x_bf16, w, bias, logits, am64, am8, B, H, W, Cin, K, stream);
 }
 
 // ------------------------------------------------------------------ head backward
@@ -104,9 +128,9 @@ extern "C" int dt_head_fwd(const float* x, const float* w, const float* bias, fl
 // dW[k][kh][kw][c] = sum_pix x[b,y+kh-1,x+kw-1,c] * dl[b,k,y,x] ; dbias[k] = sum dl
 extern "C" int dt_head_bwd_rows(int B, int H, int W) { return B * dt_cdiv(H, HEAD_TH) * dt_cdiv(W, HEAD_TW); }
 
-template <int K>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ dl, float* __restrict__ dx,
+template <int K, bool XB = false>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ dl, void* __restrict__ dx,
                                                        float* __restrict__ red, int B, int H, int W) {
   constexpr int C = HEAD_CIN;
   constexpr int HH = HEAD_TH + 2, HW_ = HEAD_TW + 2;
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-      v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + iy) * W + ix) * C + 4 * q);
+      v = head_load4<XB>(x, (((size_t)b * H + iy) * W + ix) * C + 4 * q);
 #pragma unroll
     for (int k = 0; k < 4; ++k) xt[pix][4 * q + k] = v[k];
   }
@@ -160,11 +184,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
       }
     if (valid) {
-      float* o = dx + (((size_t)b * H + oy) * W + ox) * C;
+      const size_t o = (((size_t)b * H + oy) * W + ox) * C;
 #pragma unroll
       for (int q = 0; q < C / 4; ++q) {
-        f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(o + 4 * q) = v;
+        if constexpr (XB) {
+          hbf16x4 v = {(__bf16)a[4 * q], (__bf16)a[4 * q + 1], (__bf16)a[4 * q + 2], (__bf16)a[4 * q + 3]};
+          *reinterpret_cast<hbf16x4*>(reinterpret_cast<__bf16*>(dx) + o + 4 * q) = v;
+        } else {
+          f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + o + 4 * q) = v;
+        }
       }
     }
   }
@@ -191,20 +220,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
 }
 
-extern "C" int dt_head_bwd(const float* x, const float* w, const float* dl, float* dx, float* red, int B, int H,
-                           int W, int Cin, int K, void* stream) {
+template <bool XB>
+static int head_bwd_launch(const void* x, const float* w, const float* dl, void* dx, float* red, int B, int H, int W,
+                           int Cin, int K, void* stream) {
   DT_REQUIRE(x && w && dl && dx && red && B > 0 && H > 0 && W > 0, "head_bwd: bad args");
   DT_REQUIRE(Cin == HEAD_CIN && K >= 1 && K <= HEAD_MAXK, "head_bwd: unsupported Cin/K");
   const int grid = dt_head_bwd_rows(B, H, W);
   hipStream_t st = (hipStream_t)stream;
   switch (K) {
-    case 1: hipLaunchKernelGGL(head_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
-    case 2: hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
-    case 3: hipLaunchKernelGGL(head_bwd_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
-    default: hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    case 1: hipLaunchKernelGGL((head_bwd_kernel<1, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    case 2: hipLaunchKernelGGL((head_bwd_kernel<2, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    case 3: hipLaunchKernelGGL((head_bwd_kernel<3, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    default: hipLaunchKernelGGL((head_bwd_kernel<4, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
   }
   DT_LAUNCH_CHECK();
   return DT_OK;
+}
+
+extern "C" int dt_head_bwd(const float* x, const float* w, const float* dl, float* dx, float* red, int B, int H,
+                           int W, int Cin, int K, void* stream) {
+  return head_bwd_launch<false>(x, w, dl, dx, red, B, H, W, Cin, K, stream);
+}
+
+extern "C" int dt_head_bwd_bf16(const void* x_bf16, const float* w, const float* dl, void* dx_bf16, float* red, int B,
+                                int H, int W, int Cin, int K, void* stream) {
+  return head_bwd_launch<true>(x_bf16, w, dl, dx_bf16, red, B, H, W, Cin, K, stream);
 }
 
 __global__ __launch_bounds__(256) void colsum_f64_kernel(const float* __restrict__ red, int P, int N, int pitch,

@@ -371,9 +371,14 @@ class UNetEngine:
 
         x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
         _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw.contiguous()), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
-        # stem in fp32 (K = 147, output-write bound), rounded to bf16 by its BN-apply
-        y, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, False)
-        f1 = bn_act(y, ss, y_f32=True)
+        # stem: fp32 operands (K = 147), output stored as bf16
+        stc = sp.stem
+        h, w_ = (H + 2 * stc.pad - stc.k) // stc.stride + 1, (W + 2 * stc.pad - stc.k) // stc.stride + 1
+        sdesc = self._desc(B, H, W, Cin, 0, 0, h, w_, stc.cout, stc.k, stc.stride, stc.pad)
+        y = torch.empty((B, h, w_, stc.cout), dtype=bf, device=dev)
+        _lib.check(lib.dt_conv2d_out_bf16(C.byref(sdesc), _p(x), _p(params[stc.w_off:stc.w_off + stc.w_size]), _p(y),
+                                          None, st), "dt_conv2d_out_bf16")
+        f1 = bn_act(y, affine(stc))
         hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
         pool = torch.empty((B, hp, wp, 64), dtype=bf, device=dev)
         _lib.check(lib.dt_maxpool3x3s2_bf16(_p(f1), _p(pool), B, h, w_, 64, st), "dt_maxpool3x3s2_bf16")
@@ -402,13 +407,12 @@ class UNetEngine:
             dh, dw = h2, w2
         hd = sp.head
         K = hd.cout
-        d32 = torch.empty((B, dh, dw, hd.cin), dtype=torch.float32, device=dev)
-        _lib.check(lib.dt_bf16_to_f32(_p(d), _p(d32), d.numel(), st), "dt_bf16_to_f32")
         logits = torch.empty((B, K, dh, dw), dtype=torch.float32, device=dev)
         am64 = torch.empty((B, dh, dw), dtype=torch.int64, device=dev) if want_argmax == "int64" else None
         am8 = torch.empty((B, dh, dw), dtype=torch.uint8, device=dev) if want_argmax == "uint8" else None
-        _lib.check(lib.dt_head_fwd(_p(d32), _p(params[hd.w_off:hd.w_off + hd.w_size]), _p(params[hd.b_off:hd.b_off + K]),
-                                   _p(logits), _p(am64), _p(am8), B, dh, dw, hd.cin, K, st), "dt_head_fwd")
+        _lib.check(lib.dt_head_fwd_bf16(_p(d), _p(params[hd.w_off:hd.w_off + hd.w_size]),
+                                        _p(params[hd.b_off:hd.b_off + K]), _p(logits), _p(am64), _p(am8), B, dh, dw,
+                                        hd.cin, K, st), "dt_head_fwd_bf16")
         return logits, (am64 if am64 is not None else am8)
 
     # ------------------------------------------------------------------ bf16 training (BASELINE configs[2])
@@ -461,11 +465,17 @@ class UNetEngine:
 
         x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
         _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw.contiguous()), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
-        y32, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, True)
-        f1 = bn_act(y32, ss, y_f32=True)
-        ystem = torch.empty(y32.shape, dtype=bf, device=dev)
-        _lib.check(lib.dt_f32_to_bf16(_p(y32), _p(ystem), y32.numel(), st), "dt_f32_to_bf16")
-        del y32
+        # stem: fp32 operands (K = 147), bf16 output, fp32 statistics
+        stc = sp.stem
+        h, w_ = (H + 2 * stc.pad - stc.k) // stc.stride + 1, (W + 2 * stc.pad - stc.k) // stc.stride + 1
+        sdesc = self._desc(B, H, W, Cin, 0, 0, h, w_, stc.cout, stc.k, stc.stride, stc.pad)
+        Pst = lib.dt_conv2d_stat_rows(C.byref(sdesc))
+        sstats = self._buf("bn_stats", lib.dt_bn_stats_floats(Pst, stc.cout), device=dev)
+        ystem = torch.empty((B, h, w_, stc.cout), dtype=bf, device=dev)
+        _lib.check(lib.dt_conv2d_out_bf16(C.byref(sdesc), _p(x), _p(params[stc.w_off:stc.w_off + stc.w_size]), _p(ystem),
+                                          _p(sstats), st), "dt_conv2d_out_bf16")
+        ss = finalize(stc, sstats, Pst, B * h * w_)
+        f1 = bn_act(ystem, ss)
         sv.d["stem"] = dict(x=x, y=ystem, z=f1, Hin=H, Win=W)
         hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
         pool = torch.empty((B, hp, wp, 64), dtype=bf, device=dev)
@@ -503,12 +513,11 @@ class UNetEngine:
             d, dh, dw, d_ss = nxt, h2, w2, nxt_ss
         hd = sp.head
         K = hd.cout
-        d32 = torch.empty((B, dh, dw, hd.cin), dtype=torch.float32, device=dev)
-        _lib.check(lib.dt_bf16_to_f32(_p(d), _p(d32), d.numel(), st), "dt_bf16_to_f32")
         logits = torch.empty((B, K, dh, dw), dtype=torch.float32, device=dev)
-        _lib.check(lib.dt_head_fwd(_p(d32), _p(params[hd.w_off:hd.w_off + hd.w_size]), _p(params[hd.b_off:hd.b_off + K]),
-                                   _p(logits), None, None, B, dh, dw, hd.cin, K, st), "dt_head_fwd")
-        sv.d["head"] = dict(x=d32, H=dh, W=dw)
+        _lib.check(lib.dt_head_fwd_bf16(_p(d), _p(params[hd.w_off:hd.w_off + hd.w_size]),
+                                        _p(params[hd.b_off:hd.b_off + K]), _p(logits), None, None, B, dh, dw, hd.cin, K,
+                                        st), "dt_head_fwd_bf16")
+        sv.d["head"] = dict(x=d, H=dh, W=dw)
         sv.d["B"] = B
         sv.d["bf16"] = True
         self.saved = sv
@@ -571,16 +580,14 @@ class UNetEngine:
         # ---- head (fp32) -> bf16 gradient of the last decoder activation
         hd, hsv = sp.head, S["head"]
         H, W, K = hsv["H"], hsv["W"], sp.head.cout
-        g32 = torch.empty_like(hsv["x"])
+        g = torch.empty(hsv["x"].shape, dtype=bf, device=dev)
         P = lib.dt_head_bwd_rows(B, H, W)
         red = self._buf("head_red", lib.dt_head_bwd_red_floats(B, H, W, hd.cin, K), device=dev)
-        _lib.check(lib.dt_head_bwd(_p(hsv["x"]), _p(params[hd.w_off:hd.w_off + hd.w_size]), _p(dlogits.contiguous()),
-                                   _p(g32), _p(red), B, H, W, hd.cin, K, st), "dt_head_bwd")
+        _lib.check(lib.dt_head_bwd_bf16(_p(hsv["x"]), _p(params[hd.w_off:hd.w_off + hd.w_size]),
+                                        _p(dlogits.contiguous()), _p(g), _p(red), B, H, W, hd.cin, K, st),
+                   "dt_head_bwd_bf16")
         _lib.check(lib.dt_head_bwd_finalize(_p(red), P, _p(grads[hd.w_off:hd.w_off + hd.w_size]),
                                             _p(grads[hd.b_off:hd.b_off + K]), hd.cin, K, st), "dt_head_bwd_finalize")
-        g = torch.empty(g32.shape, dtype=bf, device=dev)
-        _lib.check(lib.dt_f32_to_bf16(_p(g32), _p(g), g32.numel(), st), "dt_f32_to_bf16")
-        del g32
 
         skip_grads = [None] * 5
         for i in range(4, -1, -1):
@@ -656,9 +663,14 @@ class UNetEngine:
         _lib.check(lib.dt_maxpool3x3s2_bwd_bf16(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
                    "dt_maxpool3x3s2_bwd_bf16")
         dy = bn_bwd(sp.stem, gf1, stem["z"], stem["y"])
-        dy32 = torch.empty(dy.shape, dtype=torch.float32, device=dev)
-        _lib.check(lib.dt_bf16_to_f32(_p(dy), _p(dy32), dy.numel(), st), "dt_bf16_to_f32")
-        self._wgrad(sp.stem, grads, stem["x"], None, 0, B, stem["Hin"], stem["Win"], dy32)
+        stc = sp.stem
+        sdesc = self._desc(B, stem["Hin"], stem["Win"], stem["x"].shape[-1], 0, 0, dy.shape[1], dy.shape[2], stc.cout,
+                           stc.k, stc.stride, stc.pad)
+        nbytes = lib.dt_conv2d_wgrad_workspace(C.byref(sdesc))
+        ws = self._buf("wgrad_ws", nbytes // 4, device=dev)
+        _lib.check(lib.dt_conv2d_wgrad_stem_dy_bf16(C.byref(sdesc), _p(stem["x"]), _p(dy),
+                                                    _p(grads[stc.w_off:stc.w_off + stc.w_size]), _p(ws),
+                                                    ws.numel() * 4, st), "dt_conv2d_wgrad_stem_dy_bf16")
         self._join_side()
         if self.grad_hook:
             self.grad_hook(*sp.buckets[4])

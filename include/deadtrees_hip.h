@@ -196,6 +196,19 @@ int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, const void* sr
 int dt_bn_act_bf16(const void* y, int y_is_f32, const float* scale, const float* shift, const void* res,
                    const float* rscale, const float* rshift, void* out, int64_t n_pix, int C, int relu, void* stream);
 int dt_maxpool3x3s2_bf16(const void* x, void* out, int B, int H, int W, int C, void* stream);
+/* fp32 conv (dt_conv2d semantics, no split/accumulate/concat) storing its output as bf16 — the 7x7 stem of the
+ * bf16 path keeps fp32 operands (K = 147) but feeds bf16 activations; statistics from the fp32 accumulators. */
+int dt_conv2d_out_bf16(const dt_conv_desc* d, const float* src0, const float* w_hwio, void* out_bf16, float* stats,
+                       void* stream);
+/* stem weight gradient with the bf16 dy of the bf16 path (x fp32 image, dW fp32) */
+int dt_conv2d_wgrad_stem_dy_bf16(const dt_conv_desc* d, const float* src0, const void* dy_bf16, float* dw_hwio,
+                                 float* workspace, size_t workspace_bytes, void* stream);
+/* head with bf16 decoder activations in (forward) / bf16 activation gradient out (backward); weights, logits,
+ * dlogits and parameter gradients stay fp32 */
+int dt_head_fwd_bf16(const void* x_bf16, const float* w_ohwi, const float* bias, float* logits_nchw,
+                     int64_t* argmax_i64, uint8_t* argmax_u8, int B, int H, int W, int Cin, int K, void* stream);
+int dt_head_bwd_bf16(const void* x_bf16, const float* w_ohwi, const float* dlogits_nchw, void* dx_bf16, float* red,
+                     int B, int H, int W, int Cin, int K, void* stream);
 int dt_bf16_to_f32(const void* x, float* out, int64_t n, void* stream);
 int dt_f32_to_bf16(const float* x, void* out, int64_t n, void* stream);
 /* bf16 training passes: same contracts as their fp32 namesakes, tensors bf16, sums fp32/fp64.  `red` holds
