@@ -64,4 +64,32 @@ for name, H, W, C0, C1, mode0, Cout, k, s, p in SHAPES:
         t = e0.elapsed_time(e1) / reps * 1e-3
         res["wgrad_us"] = round(t * 1e6, 1)
         res["wgrad_TF"] = round(flops / t / 1e12, 1)
+    if "bf16" in which:
+        bf = torch.bfloat16
+        s0, s1 = src0.to(bf), (src1.to(bf) if src1 is not None else None)
+        wp = ops.pack_weights_bf16(w)
+        if k in (1, 3) and C0 % 8 == 0:
+            out0, _, _ = ops.conv2d_bf16(s0, wp, k, s, p, Cout, src1=s1, mode0=mode0, want_stats=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.conv2d_bf16(s0, wp, k, s, p, Cout, src1=s1, mode0=mode0, want_stats=True, out0=out0)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps * 1e-3
+            res["bf16_fwd_us"] = round(t * 1e6, 1)
+            res["bf16_fwd_TF"] = round(flops / t / 1e12, 1)
+            dyb = torch.randn((B, Ho, Wo, Cout), generator=g).to(bf).cuda()
+            ops.conv2d_wgrad_bf16(s0, dyb, k, s, p, src1=s1, mode0=mode0)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.conv2d_wgrad_bf16(s0, dyb, k, s, p, src1=s1, mode0=mode0)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / reps * 1e-3
+            res["bf16_wgrad_us"] = round(t * 1e6, 1)
+            res["bf16_wgrad_TF"] = round(flops / t / 1e12, 1)
     print(json.dumps(res), flush=True)
