@@ -65,6 +65,8 @@ SIGNATURES = {
     "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_confusion_matrix": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, I64, c_f, c_f, c_f]),
+    "dt_signed_distmap_workspace": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dt_signed_distmap": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_conv2d_bf16_stat_rows": (C.c_int, [_P]),
     "dt_conv2d_bf16_config": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dt_conv2d_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

@@ -14,6 +14,7 @@ from typing import Optional
 import numpy as np
 import torch
 
+from .distmap import distmaps_for_batch, distmaps_on_device
 from .synthetic import MEAN, STD, synth_batch
 
 
@@ -48,12 +49,17 @@ class _SyntheticLoader:
     def __iter__(self):
         for i in range(self.n):
             img, mask = synth_batch(self.bs, self.size, self.size, self.c, self.k, seed=self.seed + i)
-            dist = torch.zeros((self.bs, self.k, self.size, self.size), dtype=torch.float32)
+            on_gpu = bool(self.device) and str(self.device).startswith("cuda")
+            # labels headed for HBM get their maps from the device EDT kernel below; a host-only loader attaches
+            # them the way the reference's loader does (scipy, data/deadtreedata.py:182-185)
+            dist = None if (on_gpu or not self.with_distmap) else distmaps_for_batch(mask, self.k)
             lu = torch.ones_like(mask)
             stats = [{"file": f"synthetic_{self.seed + i}_{j}", "frac": float((mask[j] > 0).float().mean())}
                      for j in range(self.bs)]
             if self.device:
-                img, mask, dist, lu = (t.to(self.device) for t in (img, mask, dist, lu))
+                img, mask, lu = (t.to(self.device) for t in (img, mask, lu))
+                if self.with_distmap:
+                    dist = distmaps_on_device(mask, self.k) if on_gpu else dist.to(self.device)
             item = (img, mask, dist, lu, stats)
             yield {"main": item} if self.wrap else item
 

@@ -1,8 +1,11 @@
 """Signed distance maps for the boundary loss — the loader-side step of the reference
 (deadtrees/loss/losses.py:159-178 ``one_hot2dist`` called from data/deadtreedata.py:182-185).
 
-Host code like in the reference (scipy EDT in the loader processes); the GPU only multiplies probabilities
-with these maps (kernel `seg_loss_fwd`).  The reference allocates the result with the one-hot's INTEGER dtype,
+`distmaps_on_device` is the product path: the exact integer EDT kernel `dt_signed_distmap` (csrc/distmap.hip)
+builds the maps from the label batch already in HBM, bit-identical to the reference's scipy pass, so the loader
+no longer spends 2K scipy EDTs per sample.  `one_hot2dist` / `distmaps_for_batch` keep the reference's
+loader-side host function (scipy, as in the reference) for data pipelines that attach maps themselves.
+The reference allocates the result with the one-hot's INTEGER dtype,
 so fractional distances are truncated toward zero before the cast to float32; reproduced,
 because the boundary-loss values of the reference depend on it.
 """
@@ -32,3 +35,10 @@ def distmaps_for_batch(mask: torch.Tensor, K: int) -> torch.Tensor:
         oh = (m[i][None] == np.arange(K)[:, None, None]).astype(np.int32)
         out[i] = one_hot2dist(oh).astype(np.float32)
     return torch.from_numpy(out)
+
+
+def distmaps_on_device(mask: torch.Tensor, K: int) -> torch.Tensor:
+    """int64 labels [B,H,W] on the GPU -> float32 distance maps [B,K,H,W] on the GPU (HIP kernel, no host pass)."""
+    from .. import ops
+    d, _ = ops.signed_distmap(mask if mask.dtype == torch.int64 else mask.long(), K)
+    return d

@@ -25,6 +25,7 @@ from typing import Any, Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
+from ..data.distmap import distmaps_on_device
 from ..loss.seg_loss import seg_loss
 from ..utils.config import AttrDict, to_attrdict
 from .unet import UNetHIP
@@ -66,7 +67,8 @@ def concat_extra(img, mask, distmap, lu, stats, *, extra):
     e_img, e_mask, e_dist, e_lu, e_stats = list(zip(*extra))
     img = torch.cat((img, *e_img), dim=0)
     mask = torch.cat((mask, *e_mask), dim=0)
-    distmap = torch.cat((distmap, *e_dist), dim=0)
+    # a loader may attach no maps (None): the boundary loss then builds them on the device from the labels
+    distmap = None if distmap is None or any(d is None for d in e_dist) else torch.cat((distmap, *e_dist), dim=0)
     lu = torch.cat((lu, *e_lu), dim=0)
     stats = list(stats) + sum((list(s) for s in e_stats), [])
     return img, mask, distmap, lu, stats
@@ -157,6 +159,8 @@ class SemSegment(_Base):
         """compound loss of segmodel.py:169-200, from LOGITS and integer LABELS (fused softmax / one-hot).
         Returns (loss, parts) and logs the reference's keys."""
         use_dist = distmap if any(n.startswith("BOUNDARY") for n in self.loss_names) else None
+        if use_dist is None and any(n.startswith("BOUNDARY") for n in self.loss_names):
+            use_dist = distmaps_on_device(mask, logits.shape[1])   # loader attached none: HIP EDT on the labels
         loss, parts, err = seg_loss(logits, mask, use_dist, self.loss_names, alpha=self.alpha)
         self.label_error = err
         self.log(f"{stage}/dice_loss", parts["dice_loss"], on_step=False, on_epoch=True)

@@ -302,6 +302,22 @@ def confusion_matrix(pred, target, lu=None, K=2, counts=None):
     return counts, err
 
 
+def signed_distmap(labels: torch.Tensor, K: int):
+    """int64 labels [B,H,W] -> (fp32 distance maps [B,K,H,W], err flag) — the boundary-loss maps of
+    loss/losses.py:159-178 as attached by data/deadtreedata.py:182-185, computed exactly on the device."""
+    _gpu(labels)
+    if labels.dtype != torch.int64 or labels.dim() != 3:
+        raise RuntimeError("signed_distmap: labels must be int64 [B,H,W]")
+    B, H, W = labels.shape
+    lib = _lib.load()
+    ws = torch.empty(int(lib.dt_signed_distmap_workspace(B, K, H, W)), dtype=torch.uint8, device=labels.device)
+    dist = torch.empty((B, K, H, W), dtype=torch.float32, device=labels.device)
+    err = torch.zeros(1, dtype=torch.int32, device=labels.device)
+    _lib.check(lib.dt_signed_distmap(_p(labels.contiguous()), _p(dist), _p(ws), _p(err), B, K, H, W, _st()),
+               "dt_signed_distmap")
+    return dist, err
+
+
 class FlatAdam:
     """clip_grad_norm_(max_norm) + torch.optim.Adam on one flat buffer, two fused HIP passes
     (reference: configs/trainer/default.yaml:18 + segmodel.py:420-425)."""

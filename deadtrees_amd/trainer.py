@@ -14,6 +14,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
+from .data.distmap import distmaps_on_device
 from .loss.seg_loss import seg_loss
 from .network.unet import UNetHIP
 from .ops import FlatAdam
@@ -78,6 +79,8 @@ class HipTrainer:
         m.train()
         m.flat_params.grad = None
         logits = m(img)
+        if distmap is None and any(n.startswith("BOUNDARY") for n in self.losses):
+            distmap = distmaps_on_device(mask, logits.shape[1])
         loss, parts, err = seg_loss(logits, mask, distmap, self.losses, alpha=alpha)
         loss.backward()
         if self.reducer:
@@ -103,7 +106,8 @@ def fit(trainer: HipTrainer, loader, epochs: int, base_lr: float = 3e-4, t_max: 
         for batch in loader:
             img, mask, distmap, _, _ = create_combined_batch(batch) if isinstance(batch, dict) else batch
             if to_device:
-                img, mask, distmap = img.to(to_device), mask.to(to_device), distmap.to(to_device)
+                img, mask = img.to(to_device), mask.to(to_device)
+                distmap = distmap.to(to_device) if distmap is not None else None
             alpha = min((epoch + 1) * 0.01, 0.99)
             losses.append(trainer.step(img, mask, distmap, alpha=alpha))
         mean = float(torch.stack(losses).mean()) if losses else float("nan")

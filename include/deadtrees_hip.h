@@ -174,6 +174,16 @@ int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dis
 int dt_confusion_matrix(const int64_t* pred_i64, const uint8_t* pred_u8, const int64_t* target, const int64_t* lu,
                         int K, int64_t n, int64_t* counts, int32_t* err_flag, void* stream);
 
+/* Signed Euclidean distance maps of the boundary loss, computed on the device in place of the
+ * loader's scipy pass: data/deadtreedata.py:182-185 -> loss/losses.py:159-178 one_hot2dist(resolution=[1,1]).
+ * labels int64 [B,H,W] -> dist fp32 [B,K,H,W]; per class: floor(edt to the class) outside it, 1 - floor(edt to the
+ * outside) inside it, all zero when the class is absent (the int32 truncation of the reference included).
+ * Exact integer arithmetic: bit-identical to the reference.  workspace: dt_signed_distmap_workspace() BYTES.
+ * Labels outside [0,K) set err_flag[0] (the assert of losses.py:129). */
+int64_t dt_signed_distmap_workspace(int B, int K, int H, int W);
+int dt_signed_distmap(const int64_t* labels, float* dist, void* workspace, int32_t* err_flag, int B, int K, int H,
+                      int W, void* stream);
+
 /* ------------------------------------------------------------------ bf16 storage / fp32 accumulate (inference leg)
  * BASELINE configs[2] precision: activations NHWC bf16, weights [tap][Cout][Cin] bf16 (dt_pack_weights_bf16),
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulators, one rounding at the store.  Same descriptor semantics as
