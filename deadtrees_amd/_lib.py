@@ -62,8 +62,10 @@ SIGNATURES = {
     "dt_head_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_head_bwd_finalize": (C.c_int, [c_f, C.c_int, c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_acc_doubles": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
-    "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_gwdice_possum": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_gwdice_posgrad": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_confusion_matrix": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, I64, c_f, c_f, c_f]),
     "dt_signed_distmap_workspace": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "dt_signed_distmap": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

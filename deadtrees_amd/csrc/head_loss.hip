@@ -301,7 +301,9 @@ extern "C" int dt_head_bwd_finalize(float* red, int P, float* dw, float* dbias, 
 template <int K>
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restrict__ logits,
                                                            const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ dist, float gamma,
+                                                           const float* __restrict__ dist,
+                                                           const float* __restrict__ wassM,
+                                                           const float* __restrict__ gwV, float gamma,
                                                            double* __restrict__ part, float* __restrict__ probs,
                                                            int32_t* __restrict__ err, int64_t HW, int wg_per_img) {
   // part: [B][wg_per_img][K][NACC] fp64
@@ -315,6 +317,11 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < DT_LOSS_NACC; ++j) acc[k][j] = 0.f;
   const float* lg = logits + (size_t)b * K * HW;
+  float Mw[K][K];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int l = 0; l < K; ++l) Mw[k][l] = wassM ? wassM[k * K + l] : 0.f;
   for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
     float z[K], pr[K];
     float m = -INFINITY;
@@ -332,6 +339,27 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const float* __restri
     const float inv = 1.f / sum;
     const int64_t lab = labels[(size_t)b * HW + p];
     if (lab < 0 || lab >= K) err[0] = 1;
+    if (wassM) {
+      // GWDICE applies softmax to the PROBABILITIES once more (gwdl.py:104 on segmodel.py:176's y_hat) and
+      // weights them with the label-distance row of the pixel's class (gwdl.py:131-178)
+      float q[K], qs = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        q[k] = expf(pr[k] * inv);
+        qs += q[k];
+      }
+      const float qi = 1.f / qs;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float wass = 0.f;
+#pragma unroll
+        for (int l = 0; l < K; ++l) wass += Mw[k][l] * q[l] * qi;
+        if (lab == k) {
+          acc[k][8] += wass;
+          acc[k][9] += gwV[p];
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float pk = pr[k] * inv;
@@ -385,20 +413,21 @@ extern "C" int64_t dt_seg_loss_acc_doubles(int B, int K, int H, int W) {
 
 // scratch for partials lives behind acc: caller passes acc sized [B][K][NACC] + partial area; to keep
 // the ABI allocation-free we require acc to have room for B*(1+wg_per_img)*K*NACC doubles.
-extern "C" int dt_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dist, float gamma,
-                               double* acc, float* probs, int32_t* err_flag, int B, int K, int H, int W,
+extern "C" int dt_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dist, const float* wass_m,
+                               const float* gw_possum, float gamma, double* acc, float* probs, int32_t* err_flag, int B, int K, int H, int W,
                                void* stream) {
   DT_REQUIRE(logits && labels && acc && err_flag && B > 0 && H > 0 && W > 0, "seg_loss_fwd: bad args");
   DT_REQUIRE(K >= 2 && K <= HEAD_MAXK, "seg_loss_fwd: K=%d unsupported (2..%d)", K, HEAD_MAXK);
+  DT_REQUIRE((wass_m == nullptr) == (gw_possum == nullptr), "seg_loss_fwd: wass_m and gw_possum go together");
   const int64_t HW = (int64_t)H * W;
   const int wpi = dt_cdiv(HW, LOSS_PIX_PER_WG);
   double* part = acc + (size_t)B * K * DT_LOSS_NACC;
   hipStream_t st = (hipStream_t)stream;
   const int grid = B * wpi;
   switch (K) {
-    case 2: hipLaunchKernelGGL(seg_loss_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, logits, labels, dist, gamma, part, probs, err_flag, HW, wpi); break;
-    case 3: hipLaunchKernelGGL(seg_loss_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, logits, labels, dist, gamma, part, probs, err_flag, HW, wpi); break;
-    default: hipLaunchKernelGGL(seg_loss_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, dist, gamma, part, probs, err_flag, HW, wpi); break;
+    case 2: hipLaunchKernelGGL(seg_loss_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, logits, labels, dist, wass_m, gw_possum, gamma, part, probs, err_flag, HW, wpi); break;
+    case 3: hipLaunchKernelGGL(seg_loss_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, logits, labels, dist, wass_m, gw_possum, gamma, part, probs, err_flag, HW, wpi); break;
+    default: hipLaunchKernelGGL(seg_loss_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, dist, wass_m, gw_possum, gamma, part, probs, err_flag, HW, wpi); break;
   }
   DT_LAUNCH_CHECK();
   hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(B), dim3(64), 0, st, part, acc, wpi, K * DT_LOSS_NACC);
@@ -414,6 +443,9 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
                                                            const float* __restrict__ wfocal,
                                                            const float* __restrict__ wbound,
                                                            const float* __restrict__ gscale,
+                                                           const float* __restrict__ wassM,
+                                                           const float* __restrict__ wassC,
+                                                           const float* __restrict__ gwG,
                                                            float* __restrict__ dlogits, int64_t HW, int64_t total) {
   const float wf = wfocal[0], gamma = wfocal[1];
   const float gs = gscale ? gscale[0] : 1.f;
@@ -437,6 +469,27 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
     const float inv = 1.f / sum;
     const int64_t lab = labels[i];
     float dot = 0.f;
+    float gw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gw[k] = 0.f;
+    if (wassM && lab >= 0 && lab < K) {
+      // d loss / d p through the second softmax q = softmax(p):  g_l = (wassC[b] + gwG[p]) * M[lab][l]
+      float q[K], qs = 0.f, gq = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        q[k] = expf(pr[k] * inv);
+        qs += q[k];
+      }
+      const float qi = 1.f / qs, c = wassC[b] + gwG[p];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        q[k] *= qi;
+        gw[k] = c * wassM[lab * K + k];
+        gq += gw[k] * q[k];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) gw[k] = q[k] * (gw[k] - gq);
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const float pk = pr[k] * inv;
@@ -456,6 +509,7 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
         gk += wf * d;
       }
       if (dist && wbound) gk += wbound[k] * dist[((size_t)b * K + k) * HW + p];
+      gk += gw[k];
       g[k] = gk;
       dot += gk * pk;
     }
@@ -465,19 +519,104 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const float* __restri
 }
 
 extern "C" int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dist, const float* coef,
-                               const float* wfocal, const float* wbound, const float* gscale, float* dlogits, int B,
-                               int K, int H, int W, void* stream) {
+                               const float* wfocal, const float* wbound, const float* gscale, const float* wass_m,
+                               const float* wass_coef, const float* gw_posgrad, float* dlogits, int B, int K, int H,
+                               int W, void* stream) {
   DT_REQUIRE(logits && labels && coef && wfocal && dlogits && B > 0 && H > 0 && W > 0, "seg_loss_bwd: bad args");
   DT_REQUIRE(K >= 2 && K <= HEAD_MAXK, "seg_loss_bwd: K=%d unsupported", K);
+  DT_REQUIRE((wass_m == nullptr) == (wass_coef == nullptr) && (wass_m == nullptr) == (gw_posgrad == nullptr),
+             "seg_loss_bwd: wass_m, wass_coef and gw_posgrad go together");
   const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
   int64_t g = (total + 255) / 256;
   if (g > 256 * 16) g = 256 * 16;
   hipStream_t st = (hipStream_t)stream;
   switch (K) {
-    case 2: hipLaunchKernelGGL(seg_loss_bwd_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, dlogits, HW, total); break;
-    case 3: hipLaunchKernelGGL(seg_loss_bwd_kernel<3>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, dlogits, HW, total); break;
-    default: hipLaunchKernelGGL(seg_loss_bwd_kernel<4>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, dlogits, HW, total); break;
+    case 2: hipLaunchKernelGGL(seg_loss_bwd_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, wass_m, wass_coef, gw_posgrad, dlogits, HW, total); break;
+    case 3: hipLaunchKernelGGL(seg_loss_bwd_kernel<3>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, wass_m, wass_coef, gw_posgrad, dlogits, HW, total); break;
+    default: hipLaunchKernelGGL(seg_loss_bwd_kernel<4>, dim3((unsigned)g), dim3(256), 0, st, logits, labels, dist, coef, wfocal, wbound, gscale, wass_m, wass_coef, gw_posgrad, dlogits, HW, total); break;
   }
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ GWDICE cross-sample position sums
+// loss/gwdl.py:180-198 multiplies alpha[B,1,S] with (1 - wass)[B,S]; the shapes broadcast to [B,B,S], so the
+// "generalised true positives" of sample i are  sum_s alpha_i(s) * V(s)  with  V(s) = sum_j (1 - wass_j(s))
+// over ALL samples j.  The reference trains with that; these two small passes reproduce it:
+//   fwd:  V[s] = sum_j (1 - wass_j(s))                       (sequential over j: fixed order)
+//   bwd:  G[s] = sum_i a[i] * alpha(label_i(s)),  alpha = [k > 0]   (d loss / d wass_j(s) = G[s] + c[j])
+template <int K>
+__global__ __launch_bounds__(256) void gwdice_possum_kernel(const float* __restrict__ logits,
+                                                            const int64_t* __restrict__ labels,
+                                                            const float* __restrict__ wassM, float* __restrict__ V,
+                                                            int B, int64_t HW) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float v = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* lg = logits + (size_t)b * K * HW;
+    float z[K], m = -INFINITY, sum = 0.f, qs = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      z[k] = lg[(size_t)k * HW + p];
+      m = fmaxf(m, z[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      z[k] = expf(z[k] - m);
+      sum += z[k];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      z[k] = expf(z[k] * inv);
+      qs += z[k];
+    }
+    const float qi = 1.f / qs;
+    const int64_t lab = labels[(size_t)b * HW + p];
+    float wass = 0.f;
+    if (lab >= 0 && lab < K) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) wass += wassM[lab * K + k] * z[k] * qi;
+    }
+    v += 1.f - wass;
+  }
+  V[p] = v;
+}
+
+__global__ __launch_bounds__(256) void gwdice_posgrad_kernel(const int64_t* __restrict__ labels,
+                                                             const float* __restrict__ a, float* __restrict__ G,
+                                                             int B, int64_t HW) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float g = 0.f;
+  for (int b = 0; b < B; ++b)
+    if (labels[(size_t)b * HW + p] > 0) g += a[b];
+  G[p] = g;
+}
+
+extern "C" int dt_gwdice_possum(const float* logits, const int64_t* labels, const float* wass_m, float* possum, int B,
+                                int K, int H, int W, void* stream) {
+  DT_REQUIRE(logits && labels && wass_m && possum && B > 0 && H > 0 && W > 0, "gwdice_possum: bad args");
+  DT_REQUIRE(K >= 2 && K <= HEAD_MAXK, "gwdice_possum: K=%d unsupported", K);
+  const int64_t HW = (int64_t)H * W;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(dt_cdiv(HW, 256));
+  switch (K) {
+    case 2: hipLaunchKernelGGL(gwdice_possum_kernel<2>, grid, dim3(256), 0, st, logits, labels, wass_m, possum, B, HW); break;
+    case 3: hipLaunchKernelGGL(gwdice_possum_kernel<3>, grid, dim3(256), 0, st, logits, labels, wass_m, possum, B, HW); break;
+    default: hipLaunchKernelGGL(gwdice_possum_kernel<4>, grid, dim3(256), 0, st, logits, labels, wass_m, possum, B, HW); break;
+  }
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+extern "C" int dt_gwdice_posgrad(const int64_t* labels, const float* sample_coef, float* posgrad, int B, int H, int W,
+                                 void* stream) {
+  DT_REQUIRE(labels && sample_coef && posgrad && B > 0 && H > 0 && W > 0, "gwdice_posgrad: bad args");
+  const int64_t HW = (int64_t)H * W;
+  hipLaunchKernelGGL(gwdice_posgrad_kernel, dim3(dt_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, labels,
+                     sample_coef, posgrad, B, HW);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -131,17 +131,15 @@ class SemSegment(_Base):
         assert (("GDICE" in losses) and ("DICE" in losses)) is False, f"Only GDICE _OR_ DICE allowed {losses}"
         self.loss_names = []
         for comp in losses:
-            if comp in ("GDICE", "DICE", "FOCAL", "BOUNDARY"):
+            if comp in ("GDICE", "GWDICE", "DICE", "FOCAL", "BOUNDARY"):
                 self.loss_names.append(comp)
             elif comp == "BOUNDARY-RAMPED":
                 self.loss_names.append(comp)
                 self.boundary_loss_ramped = True
-            elif comp == "GWDICE":
-                raise NotImplementedError("GWDICE is not on the MI355X hot path yet (SURVEY.md §8 f4)")
             else:
                 raise NotImplementedError(f"The loss component <{comp}> is not recognized")
         log.info(f"Losses: {losses}")
-        assert any(n in ("GDICE", "DICE") for n in self.loss_names)  # "we require GDICE!" (segmodel.py:143)
+        assert any(n in ("GDICE", "GWDICE", "DICE") for n in self.loss_names)  # "we require GDICE!" (segmodel.py:143)
 
         self.stats = {"train": Counter(), "val": Counter(), "test": Counter()}
         self.label_error = None  # device flag: labels outside [0,K) seen (class2one_hot's assert, lazily)

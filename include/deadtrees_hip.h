@@ -150,23 +150,39 @@ int dt_head_bwd(const float* x, const float* w_ohwi, const float* dlogits_nchw, 
 int dt_head_bwd_finalize(float* red, int P, float* dw_ohwi, float* dbias, int Cin, int K, void* stream);
 
 /* ------------------------------------------------------------------ losses & metrics (K12-K18) */
-#define DT_LOSS_NACC 8
+#define DT_LOSS_NACC 10
 /* per (b,k) accumulators, fp64 [B][K][DT_LOSS_NACC]:
  *   0 count(t)  1 sum p*t  2 sum p  3 sum (1-p)^gamma * t * log(p+1e-10)  4 sum t*log(p+1e-10)
  *   5 sum p*dist  6 sum t*[p>0.5]  7 sum [p>0.5]
+ *   8 sum t * wass, wass = sum_l M[label][l] * softmax(p)_l  (GWDICE, loss/gwdl.py:131-178; only when wass_m given:
+ *     K x K label-distance matrix, row-major; note the SECOND softmax over the probabilities, segmodel.py:176)
+ *   9 sum t * V(pixel), V = gw_possum from dt_gwdice_possum (the cross-sample sum the reference's broadcasting
+ *     in gwdl.py:180-198 produces); wass_m and gw_possum are both NULL unless GWDICE is on.
  * from logits (softmax fused, never materialising the int32 one-hot of losses.py:124-141).
  * labels int64 [B,H,W]; dist may be NULL.  Also optionally writes probs[B,K,H,W].
  * acc must have room for dt_seg_loss_acc_doubles(B,K,H,W) doubles: the [B][K][NACC] result first,
  * per-workgroup partial rows behind it (fixed-order second stage, no atomics).
  * Labels outside [0,K) (the assert of losses.py:129) set err_flag[0]=1 instead of aborting the kernel. */
 int64_t dt_seg_loss_acc_doubles(int B, int K, int H, int W);
-int dt_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dist, float gamma,
-                    double* acc, float* probs, int32_t* err_flag, int B, int K, int H, int W, void* stream);
+int dt_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dist, const float* wass_m,
+                    const float* gw_possum, float gamma, double* acc, float* probs, int32_t* err_flag, int B, int K, int H, int W, void* stream);
 /* dlogits = softmax-backward of g, g_k = a[b,k]*t_k + c[b,k] + wf*focal'(p_k)*t_k + wb[k]*dist_k,
- * scaled by gscale[0] (device scalar: upstream grad); coef fp32 [B][K][2] = (a,c); wfocal = [wf/M, gamma]. */
+ * scaled by gscale[0] (device scalar: upstream grad); coef fp32 [B][K][2] = (a,c); wfocal = [wf/M, gamma].
+ * GWDICE (all NULL when unused): wass_m [K][K]; d loss / d wass of pixel (b, s) = wass_coef[b] + gw_posgrad[s]
+ * (fp32 [B] and [H*W], the latter from dt_gwdice_posgrad); chained through the second softmax before it joins g. */
 int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dist, const float* coef,
-                    const float* wfocal, const float* wbound, const float* gscale, float* dlogits,
-                    int B, int K, int H, int W, void* stream);
+                    const float* wfocal, const float* wbound, const float* gscale, const float* wass_m,
+                    const float* wass_coef, const float* gw_posgrad, float* dlogits, int B, int K, int H, int W,
+                    void* stream);
+/* GWDICE position passes.  loss/gwdl.py:180-198 broadcasts alpha[B,1,S] * (1 - wass)[B,S] to [B,B,S], so sample
+ * i's generalised true positives are sum_s alpha_i(s) * V(s), V(s) = sum_j (1 - wass_j(s)) over the whole batch
+ * (equal to the published formula only for B = 1); reproduced because the reference trains with it.
+ *   dt_gwdice_possum : possum[H*W] = V                                   (forward, before dt_seg_loss_fwd)
+ *   dt_gwdice_posgrad: posgrad[H*W] = sum_i sample_coef[i] * [label_i(s) > 0]   (backward, before dt_seg_loss_bwd) */
+int dt_gwdice_possum(const float* logits, const int64_t* labels, const float* wass_m, float* possum, int B, int K,
+                     int H, int W, void* stream);
+int dt_gwdice_posgrad(const int64_t* labels, const float* sample_coef, float* posgrad, int B, int H, int W,
+                      void* stream);
 
 /* K x K confusion counts accumulated on the device (eval reductions, segmodel.py:291-309,337-365):
  * counts int64 [2][K][K] (+=): plane 0 all pixels, plane 1 pixels with lu == 1 (lu may be NULL);

@@ -68,6 +68,31 @@ def boundary(p: torch.Tensor, distmap: torch.Tensor, idc) -> torch.Tensor:
     return (p.to(torch.float64)[:, idc] * distmap.to(torch.float64)[:, idc]).mean()
 
 
+GWDICE_M3 = [[0.0, 1.0, 1.0], [1.0, 0.0, 0.5], [1.0, 0.5, 0.0]]  # reference segmodel.py:119
+
+
+def gwdice(p: torch.Tensor, mask: torch.Tensor, M=None) -> torch.Tensor:
+    """reference loss/gwdl.py:84-138 ``GeneralizedWassersteinDiceLoss`` (weighting_mode "default", reduction
+    "mean") as SemSegment calls it (segmodel.py:117-124,176): the input is already a PROBABILITY map and the loss
+    applies softmax to it once more (gwdl.py:104); M defaults to the matrix of segmodel.py:119 cut to K classes.
+    Differentiable; works in the dtype of ``p``."""
+    B, K = p.shape[0], p.shape[1]
+    Mt = torch.tensor(GWDICE_M3 if M is None else M, dtype=p.dtype)[:K, :K]
+    eps = float(np.spacing(1))
+    q = p.reshape(B, K, -1).softmax(dim=1)                      # gwdl.py:100-104
+    t = mask.reshape(B, -1)
+    wass = (Mt[t].permute(0, 2, 1) * q).sum(dim=1)              # gwdl.py:131-178: sum_l M[t_s, l] q_l
+    alpha = torch.ones(K, dtype=p.dtype)
+    alpha[0] = 0.0                                              # gwdl.py:246-252
+    # gwdl.py:180-198 multiplies alpha [B,1,S] with (1 - wass) [B,S]: the shapes broadcast to [B,B,S], so the
+    # "true positives" of sample i sum alpha_i(s) * (1 - wass_j(s)) over EVERY sample j of the batch.  The
+    # reference trains with that; it is reproduced (it reduces to the published formula for B = 1).
+    tp = (alpha[t] * (1.0 - wass).sum(dim=0, keepdim=True)).sum(dim=1)
+    all_err = wass.sum(dim=1)
+    dice_ = (2.0 * tp + eps) / (2.0 * tp + all_err + eps)       # gwdl.py:126-128
+    return (1.0 - dice_).mean()
+
+
 def dist_map(onehot_sample: np.ndarray) -> np.ndarray:
     """reference losses.py:159-178 ``one_hot2dist`` with ``resolution=[1,1]`` as called from
     deadtrees/data/deadtreedata.py:182-185.  NOTE the reference allocates the result with the

@@ -10,9 +10,9 @@ INPUTS and OUTPUTS as data.  No reference source text is stored.  The fixtures t
 box; the reference does not.
 
 G1 losses   : cases (seed,B,K,H,W); logits f32, mask i64 (incl. an all-background sample and a
-              class-missing case) -> one-hot checksum, GDICE, DICE, FOCAL(g=2), CE, BOUNDARY (int32
+              class-missing case) -> one-hot checksum, GDICE, DICE, GWDICE, FOCAL(g=2), CE, BOUNDARY (int32
               truncated distance maps, as the loader produces them) and d(loss)/d(logits) from
-              autograd through the reference callables for GDICE+FOCAL, DICE+FOCAL, +BOUNDARY.
+              autograd through the reference callables for GDICE+FOCAL, DICE+FOCAL, +BOUNDARY, GWDICE+FOCAL.
 G2 blocks   : make/unmake_blocks_vectorized on the toy of reference tests/test_tiler.py:57-65 and
               on a random (4,512,512) uint8 array split into 256-blocks.
 """
@@ -43,6 +43,7 @@ def _labels(g, B, K, H, W, force_bg=True, drop_class=None):
 def main():
     sys.path.insert(0, "/root/reference")
     from deadtrees.loss.gdl import GeneralizedDiceLoss
+    from deadtrees.loss.gwdl import GeneralizedWassersteinDiceLoss
     from deadtrees.loss.losses import (BoundaryLoss, CrossEntropy, DiceLoss, FocalLoss,
                                        class2one_hot, one_hot2dist)
     from deadtrees.utils.data_handling import make_blocks_vectorized, unmake_blocks_vectorized
@@ -70,14 +71,19 @@ def main():
         out["focal"] = FocalLoss(idc=idc_all, gamma=2)(p, y).item()
         out["ce"] = CrossEntropy(idc=idc_all)(p, y).item()
         out["boundary"] = BoundaryLoss(idc=idc_fg)(p, distf).item()
+        gw_m = np.array([[0.0, 1.0, 1.0], [1.0, 0.0, 0.5], [1.0, 0.5, 0.0]])[:K, :K]  # segmodel.py:119-121
+        gwdl = GeneralizedWassersteinDiceLoss(dist_matrix=gw_m)
+        out["gwdice"] = gwdl(p, torch.argmax(y, dim=1)).item()                      # the call of segmodel.py:176
         combos = {"GDICE+FOCAL": ("g", "f"), "DICE+FOCAL": ("d", "f"),
-                  "GDICE+BOUNDARY+FOCAL": ("g", "b", "f")}
+                  "GDICE+BOUNDARY+FOCAL": ("g", "b", "f"), "GWDICE+FOCAL": ("w", "f")}
         for name, parts in combos.items():
             lg = logits.clone().requires_grad_(True)
             pp = lg.softmax(dim=1)
             tot = 0
             if "g" in parts:
                 tot = tot + GeneralizedDiceLoss()(pp, y)
+            if "w" in parts:
+                tot = tot + gwdl(pp, torch.argmax(y, dim=1))
             if "d" in parts:
                 tot = tot + DiceLoss(idc=idc_fg)(pp, y)
             if "b" in parts:

@@ -57,9 +57,14 @@ def loss_from_logits(logits, mask, losses=("GDICE", "FOCAL"), distmap=None, alph
     t = onehot_f32(mask, K)
     p = logits.softmax(dim=1)
     total = 0
-    if "GDICE" in losses:
+    kind = [n for n in losses if n in ("GDICE", "DICE", "GWDICE")]
+    kind = kind[-1] if kind else None      # reference segmodel.py:113-127: the later entry wins
+    if kind == "GWDICE":
+        from .losses_ref import gwdice
+        total = total + gwdice(p, mask)
+    elif kind == "GDICE":
         total = total + gdice_t(p, t)
-    elif "DICE" in losses:
+    elif kind == "DICE":
         total = total + dice_t(p, t, list(range(1, K)))
     if ("BOUNDARY" in losses or "BOUNDARY-RAMPED" in losses) and distmap is not None:
         total = total + (alpha if "BOUNDARY-RAMPED" in losses else 1.0) * boundary_t(

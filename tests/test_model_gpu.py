@@ -131,7 +131,7 @@ def test_fused_losses_vs_reference_golden(path):
     z = np.load(path)
     mask = torch.from_numpy(z["mask"]).to(DEV)
     dist = torch.from_numpy(z["distmap"]).to(DEV)
-    for combo in ("GDICE+FOCAL", "DICE+FOCAL", "GDICE+BOUNDARY+FOCAL"):
+    for combo in ("GDICE+FOCAL", "DICE+FOCAL", "GDICE+BOUNDARY+FOCAL", "GWDICE+FOCAL"):
         names = tuple(combo.split("+"))
         lg = torch.from_numpy(z["logits"]).to(DEV).requires_grad_(True)
         total, parts, err = seg_loss(lg, mask, dist if "BOUNDARY" in names else None, names)
@@ -140,7 +140,9 @@ def test_fused_losses_vs_reference_golden(path):
         assert float(total.detach()) == pytest.approx(float(z[f"loss[{combo}]"]), rel=1e-5, abs=1e-6)
         ref = z[f"dlogits[{combo}]"]
         np.testing.assert_allclose(lg.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max() + 1e-10)
-        if "GDICE" in names:
+        if "GWDICE" in names:   # incl. the cross-sample broadcast of gwdl.py:180-198 (B > 1 in every fixture)
+            assert float(parts["dice_loss"]) == pytest.approx(float(z["gwdice"]), rel=1e-5, abs=1e-6)
+        elif "GDICE" in names:
             assert float(parts["dice_loss"]) == pytest.approx(float(z["gdice"]), rel=1e-5, abs=1e-6)
         else:
             assert float(parts["dice_loss"]) == pytest.approx(float(z["dice"]), rel=1e-5, abs=1e-6)

@@ -37,6 +37,7 @@ def test_loss_values(path):
     assert float(L.focal(p, mask, al, 2.0)) == pytest.approx(float(z["focal"]), rel=2e-6, abs=2e-7)
     assert float(L.cross_entropy(p, mask, al)) == pytest.approx(float(z["ce"]), rel=2e-6, abs=2e-7)
     assert float(L.boundary(p, dist, fg)) == pytest.approx(float(z["boundary"]), rel=2e-6, abs=2e-6)
+    assert float(L.gwdice(p.double(), mask)) == pytest.approx(float(z["gwdice"]), rel=2e-6, abs=2e-7)
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
@@ -50,7 +51,7 @@ def test_distmap_restatement(path):
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
-@pytest.mark.parametrize("combo", ["GDICE+FOCAL", "DICE+FOCAL", "GDICE+BOUNDARY+FOCAL"])
+@pytest.mark.parametrize("combo", ["GDICE+FOCAL", "DICE+FOCAL", "GDICE+BOUNDARY+FOCAL", "GWDICE+FOCAL"])
 def test_differentiable_restatement_grads(path, combo):
     """train_ref.loss_from_logits (used by the CPU baseline / gradient oracle) vs autograd through
     the imported reference losses."""
