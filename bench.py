@@ -62,7 +62,9 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    distributed = world > 1
+    # DT_FORCE_DIST=1 runs the RCCL process group even at world size 1 (exercises init / broadcast / bucketed
+    # all-reduce / barrier on a 1-GPU box under torch.distributed.run)
+    distributed = world > 1 or os.environ.get("DT_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
