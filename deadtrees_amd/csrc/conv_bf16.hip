@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   constexpr int NT = TN / 32;
   constexpr int IN_ROWS = G::HALO_H * G::HALO_W;
   constexpr int W_ROWS = G::TAPS * TN;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[(IN_ROWS + W_ROWS) * BF_PITCH];
+  constexpr int OUT_PITCH = TN + 8;   // bf16 per pixel row of the store-staging image (16-B aligned rows)
+  constexpr int LDS_MAIN = (IN_ROWS + W_ROWS) * BF_PITCH, LDS_OUT = 256 * OUT_PITCH;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT];
   __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 2 * BF_TF_MAXC : 4];
   __bf16* lds_in = lds;
   __bf16* lds_w = lds + IN_ROWS * BF_PITCH;
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
       const int kh = tap / KS, kw = tap % KS;
 #pragma unroll
       for (int ks = 0; ks < BF_CK / 16; ++ks) {
+        if (c0 + 16 * ks >= Cin) continue;   // Cin = 16 (mod 32): the second k-step of the last chunk is all zero
         bf16x8 av[2], bv[NT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -196,6 +199,48 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   float s1[NT], s2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+  // Plain stores go through LDS: a lane owns ONE channel of 16 pixels (2-byte scattered stores, 64 B runs);
+  // staged pixel-major, every lane then writes 16 B and a wave covers whole NHWC pixel rows.
+  const int ld_all = a.cout_split > 0 ? (n0 >= a.cout_split ? a.Cout - a.cout_split : a.cout_split) : a.Cout;
+  const bool staged = !a.accumulate && (ld_all & 7) == 0;
+  if (staged) {
+    __syncthreads();   // every wave is done with the operand images
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int p = (wave * 2 + mt) * 32 + mrow;
+          const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+          const float v = acc[mt][j][i];
+          if (n0 + 32 * j + r < a.Cout && oy < a.Ho && ox < a.Wo) {
+            s1[j] += v;
+            s2[j] += v * v;
+          }
+          lds[p * OUT_PITCH + 32 * j + r] = (__bf16)v;
+        }
+    __syncthreads();
+    __bf16* outp = a.out;
+    int nn0 = n0;
+    if (a.cout_split > 0 && n0 >= a.cout_split) {
+      outp = a.out1;
+      nn0 = n0 - a.cout_split;
+    }
+    constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS;
+    const int seg = tid % SEGS, prow = tid / SEGS;
+    if (n0 + 8 * seg < a.Cout) {
+#pragma unroll
+      for (int it = 0; it < SEGS; ++it) {
+        const int p = prow + it * PER_IT;
+        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        if (oy < a.Ho && ox < a.Wo)
+          *reinterpret_cast<f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) =
+              *reinterpret_cast<const f32x4*>(lds + p * OUT_PITCH + 8 * seg);
+      }
+    }
+  } else
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + 32 * j + r;
@@ -556,7 +601,11 @@ struct WgradBfArgs {
 #define WB_PITCH 72   // bf16 elements per LDS row (64 used): 144 bytes (multiple of 8 for the transposed reads)
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
-template <int KS, int STRIDE, int TW, bool TF>
+// BLK = 64: a workgroup owns a 64ci x 64co block, its 4 waves split the channels 2 x 2.
+// BLK = 32 (layers with Cin, Cout <= 32 — the full-resolution decoder end, HBM-bound in bf16): one 32 x 32 block,
+// the 4 waves split the PIXEL rows of each tile instead and are summed through LDS once at the end, so no wave
+// multiplies zero padding.
+template <int KS, int STRIDE, int TW, bool TF, int BLK>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfArgs a) {
   constexpr int TPX = 128, TH = TPX / TW;
   constexpr int LS = (KS == 1) ? 1 : STRIDE, GS = (KS == 1) ? STRIDE : 1;
@@ -569,16 +618,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
   __bf16* ly = lds + X_ROWS * WB_PITCH;
   const int wgid = (int)xcd_remap(blockIdx.x, gridDim.x);
   const int blk = wgid % (a.ci_blocks * a.co_blocks), ks = wgid / (a.ci_blocks * a.co_blocks);
-  const int ci0 = (blk / a.co_blocks) * 64, co0 = (blk % a.co_blocks) * 64;
+  const int ci0 = (blk / a.co_blocks) * BLK, co0 = (blk % a.co_blocks) * BLK;
   const int Cin = a.C0 + a.C1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wci = wave >> 1, wco = wave & 1;
+  const int wci = BLK == 64 ? (wave >> 1) : 0, wco = BLK == 64 ? (wave & 1) : 0;
   // transposed-read lane roles: group g = lane>>4 -> channel half (g&1), pixel half h = lane>>5; q,p inside the group
   const int h = lane >> 5, gsel = (lane >> 4) & 1, q4 = (lane >> 2) & 3, p4 = lane & 3;
   const int xlane = (8 * h + q4) * LS * WB_PITCH + wci * 32 + 16 * gsel + 4 * p4;
   const int ylane = (8 * h + q4) * WB_PITCH + wco * 32 + 16 * gsel + 4 * p4;
   if constexpr (TF) {
-    if (tid < 64 && ci0 + tid < a.C0) {
+    if (tid < BLK && ci0 + tid < a.C0) {
       lds_tf[tid] = a.in_scale[ci0 + tid];
       lds_tf[64 + tid] = a.in_shift[ci0 + tid];
     }
@@ -589,10 +638,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // staging: 8 x 16-byte segments (8 channels) per pixel row
-  constexpr int X_TOTAL = X_ROWS * 8, X_IT = (X_TOTAL + 255) / 256;
-  constexpr int Y_TOTAL = TPX * 8, Y_IT = (Y_TOTAL + 255) / 256;
-  const int q8 = tid & 7, prow0 = tid >> 3;
+  // staging: BLK/8 x 16-byte segments (8 channels) per pixel row
+  constexpr int SEGS = BLK / 8, ROWS_IT = 256 / SEGS;
+  constexpr int X_TOTAL = X_ROWS * SEGS, X_IT = (X_TOTAL + 255) / 256;
+  constexpr int Y_TOTAL = TPX * SEGS, Y_IT = (Y_TOTAL + 255) / 256;
+  const int q8 = tid % SEGS, prow0 = tid / SEGS;
   const int cx = ci0 + 8 * q8;
   const bool x_use0 = cx < a.C0;
   const __bf16* xsrc = x_use0 ? a.src0 : a.src1;
@@ -611,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
     unsigned xvalid = 0;
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
-      const int pix = prow0 + it * 32;
+      const int pix = prow0 + it * ROWS_IT;
       const int hy = pix / HALO_W, hx = pix - hy * HALO_W;
       const int iy = iy0 + hy * GS, ix = ix0 + hx * GS;
       bool ok = x_ch_ok && pix < X_ROWS && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
@@ -624,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
     }
 #pragma unroll
     for (int it = 0; it < Y_IT; ++it) {
-      const int pix = prow0 + it * 32;
+      const int pix = prow0 + it * ROWS_IT;
       const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (y_ch_ok && pix < TPX && oy < a.Ho && ox < a.Wo)
@@ -634,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
-      const int pix = prow0 + it * 32;
+      const int pix = prow0 + it * ROWS_IT;
       if (pix < X_ROWS) {
         f32x4 raw = rx[it];
         if (TF && x_tf && ((xvalid >> it) & 1u)) {
@@ -652,13 +702,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
     }
 #pragma unroll
     for (int it = 0; it < Y_IT; ++it) {
-      const int pix = prow0 + it * 32;
+      const int pix = prow0 + it * ROWS_IT;
       if (pix < TPX) *reinterpret_cast<f32x4*>(ly + pix * WB_PITCH + 8 * q8) = ry[it];
     }
     __syncthreads();
     typedef bf16x4v __attribute__((address_space(3))) * lds_ptr;
+    constexpr int ROWS_W = BLK == 64 ? TH : TH / 4;   // BLK 32: this wave's share of the tile's pixel rows
+    const int row_w0 = BLK == 64 ? 0 : wave * ROWS_W;
 #pragma unroll
-    for (int row = 0; row < TH; ++row) {
+    for (int rr = 0; rr < ROWS_W; ++rr) {
+      const int row = row_w0 + rr;
 #pragma unroll
       for (int xs = 0; xs < TW / 16; ++xs) {
         // B fragment: dy pixels (row, 16*xs + 8h .. +7), channels of this wave's co tile
@@ -690,6 +743,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
       }
     }
   }
+  if constexpr (BLK == 32) {
+    // sum the four pixel shares in wave 0 (fixed order 1, 2, 3 -> deterministic)
+    float* red = reinterpret_cast<float*>(lds);   // [TAPS][16][64] fp32 <= 36 KB, inside the operand images
+    static_assert((size_t)TAPS * 16 * 64 * sizeof(float) <= sizeof(lds), "reduction image must fit the tiles");
+    for (int w = 1; w < 4; ++w) {
+      __syncthreads();
+      if (wave == w) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) red[(t * 16 + i) * 64 + lane] = acc[t][i];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][i] += red[(t * 16 + i) * 64 + lane];
+      }
+    }
+    if (wave != 0) return;
+  }
   const int part = ks;
   const int r = lane & 31;
   const int co = co0 + wco * 32 + r;
@@ -707,8 +782,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfAr
 static int wb_cfg(const dt_conv_desc* d, int* tw, int* ksplit, int* T, int* cib, int* cob) {
   const int Cin = d->C0 + d->C1;
   *tw = d->Wo > 16 ? 32 : 16;
-  *cib = dt_cdiv(Cin, 64);
-  *cob = dt_cdiv(d->Cout, 64);
+  const int blk = (Cin <= 32 && d->Cout <= 32 && d->ksize == 3 && d->stride == 1) ? 32 : 64;
+  *cib = dt_cdiv(Cin, blk);
+  *cob = dt_cdiv(d->Cout, blk);
   const int th = 128 / *tw;
   *T = d->B * dt_cdiv(d->Ho, th) * dt_cdiv(d->Wo, *tw);
   int ks = 512 / (*cib * *cob);
@@ -751,10 +827,21 @@ __global__ __launch_bounds__(256) void wgrad_bf16_final_kernel(const float* __re
 
 template <int KS, int STRIDE, int TW>
 static int wb_launch(const WgradBfArgs& a, int grid, hipStream_t st) {
+  const bool narrow = a.C0 + a.C1 <= 32 && a.Cout <= 32;
+  if (narrow) {
+    if constexpr (KS == 3 && STRIDE == 1) {
+      if (a.in_scale != nullptr)
+        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, true, 32>), dim3(grid), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, false, 32>), dim3(grid), dim3(256), 0, st, a);
+      DT_LAUNCH_CHECK();
+      return DT_OK;
+    }
+  }
   if (a.in_scale != nullptr)
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, true>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, true, 64>), dim3(grid), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, false>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<KS, STRIDE, TW, false, 64>), dim3(grid), dim3(256), 0, st, a);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

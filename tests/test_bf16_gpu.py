@@ -115,12 +115,14 @@ def test_wgrad_bf16(B, H, W, Cin, Cout, k, s, p):
     assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
 
 
-def test_wgrad_bf16_upsample_concat_transform():
+@pytest.mark.parametrize("C0,C1,Cout,h,w_", [(64, 64, 32, 8, 8), (32, 0, 16, 20, 24), (16, 16, 32, 8, 40)])
+def test_wgrad_bf16_upsample_concat_transform(C0, C1, Cout, h, w_):
+    """decoder shapes incl. the 32-channel-block kernel (Cin, Cout <= 32: waves split the pixel rows)"""
     ops = _ops()
     g = torch.Generator().manual_seed(21)
-    B, h, w_, C0, C1, Cout = 2, 8, 8, 64, 64, 32
+    B = 2
     a = torch.randn((B, C0, h, w_), generator=g)
-    skip = torch.randn((B, C1, 2 * h, 2 * w_), generator=g)
+    skip = torch.randn((B, max(C1, 8), 2 * h, 2 * w_), generator=g)[:, :C1]
     sc = 1 + 0.3 * torch.randn(C0, generator=g)
     sh = 0.3 * torch.randn(C0, generator=g) + 0.4
     ag, a64 = bf(a)
@@ -131,7 +133,8 @@ def test_wgrad_bf16_upsample_concat_transform():
     dy = torch.randn(y.shape, generator=g)
     dyg, dy64 = bf(dy)
     y.backward(dy64)
-    dw = ops.conv2d_wgrad_bf16(ag, dyg, 3, 1, 1, src1=sg, mode0=1, in_scale=sc.to(DEV), in_shift=sh.to(DEV))
+    dw = ops.conv2d_wgrad_bf16(ag, dyg, 3, 1, 1, src1=sg if C1 else None, mode0=1, in_scale=sc.to(DEV),
+                               in_shift=sh.to(DEV))
     got = dw.cpu().permute(3, 2, 0, 1).double()
     assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
 
