@@ -48,8 +48,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   constexpr int IN_ROWS = G::HALO_H * G::HALO_W;
   constexpr int W_ROWS = G::TAPS * TN;
   constexpr int OUT_PITCH = TN + 8;   // bf16 per pixel row of the store-staging image (16-B aligned rows)
+  constexpr int OUTF_PITCH = TN + 4;  // fp32 per pixel row of the gradient-join staging image
   constexpr int LDS_MAIN = (IN_ROWS + W_ROWS) * BF_PITCH, LDS_OUT = 256 * OUT_PITCH;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT];
+  constexpr int LDS_OUTF = 256 * OUTF_PITCH * 2;   // in bf16 elements
+  static_assert(LDS_OUTF >= LDS_OUT, "fp32 staging is the larger image");
+  __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_MAIN > LDS_OUTF ? LDS_MAIN : LDS_OUTF];
   __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 2 * BF_TF_MAXC : 4];
   __bf16* lds_in = lds;
   __bf16* lds_w = lds + IN_ROWS * BF_PITCH;
@@ -199,12 +202,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   float s1[NT], s2[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-  // Plain stores go through LDS: a lane owns ONE channel of 16 pixels (2-byte scattered stores, 64 B runs);
-  // staged pixel-major, every lane then writes 16 B and a wave covers whole NHWC pixel rows.
-  const int ld_all = a.cout_split > 0 ? (n0 >= a.cout_split ? a.Cout - a.cout_split : a.cout_split) : a.Cout;
-  const bool staged = !a.accumulate && (ld_all & 7) == 0;
-  if (staged) {
-    __syncthreads();   // every wave is done with the operand images
+  // Stores go through LDS: a lane owns ONE channel of 16 pixels (2-byte scattered accesses, 64 B runs); staged
+  // pixel-major, every lane then moves 16 B and a wave covers whole NHWC pixel rows.  Plain stores stage the
+  // rounded bf16 values; gradient joins (accumulate) stage the fp32 accumulators, add the bf16 value already in
+  // memory and round ONCE.
+  const bool second = a.cout_split > 0 && n0 >= a.cout_split;
+  const int ld_all = a.cout_split > 0 ? (second ? a.Cout - a.cout_split : a.cout_split) : a.Cout;
+  __bf16* outp = second ? a.out1 : a.out;
+  const int nn0 = second ? n0 - a.cout_split : n0;
+  const bool join = a.accumulate && !second;
+  constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS;
+  const int seg = tid % SEGS, prow = tid / SEGS;
+  __syncthreads();   // every wave is done with the operand images
+  if (!join) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -222,14 +232,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
           lds[p * OUT_PITCH + 32 * j + r] = (__bf16)v;
         }
     __syncthreads();
-    __bf16* outp = a.out;
-    int nn0 = n0;
-    if (a.cout_split > 0 && n0 >= a.cout_split) {
-      outp = a.out1;
-      nn0 = n0 - a.cout_split;
-    }
-    constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS;
-    const int seg = tid % SEGS, prow = tid / SEGS;
     if (n0 + 8 * seg < a.Cout) {
 #pragma unroll
       for (int it = 0; it < SEGS; ++it) {
@@ -240,48 +242,45 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
               *reinterpret_cast<const f32x4*>(lds + p * OUT_PITCH + 8 * seg);
       }
     }
-  } else
+  } else {
+    float* ldsf = reinterpret_cast<float*>(lds);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + 32 * j + r;
-    __bf16* outp = a.out;
-    int ld = a.Cout, nn = n;
-    if (a.cout_split > 0) {
-      if (n0 >= a.cout_split) {
-        outp = a.out1; ld = a.Cout - a.cout_split; nn = n - a.cout_split;
-      } else {
-        ld = a.cout_split;
-      }
-    }
-    const bool nok = n < a.Cout;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      size_t off[16];
-      bool ok[16];
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int p = (wave * 2 + mt) * 32 + mrow;
+        for (int i = 0; i < 16; ++i) {
+          const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int p = (wave * 2 + mt) * 32 + mrow;
+          ldsf[p * OUTF_PITCH + 32 * j + r] = acc[mt][j][i];
+        }
+    __syncthreads();
+    if (n0 + 8 * seg < a.Cout) {
+      f32x4 prev[SEGS];
+#pragma unroll
+      for (int it = 0; it < SEGS; ++it) {
+        const int p = prow + it * PER_IT;
         const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        ok[i] = nok && oy < a.Ho && ox < a.Wo;
-        off[i] = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld + nn;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (oy < a.Ho && ox < a.Wo)
+          v = *reinterpret_cast<const f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg);
+        prev[it] = v;
       }
-      if (a.accumulate && outp == a.out) {
-        float prev[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) prev[i] = ok[i] ? (float)outp[off[i]] : 0.f;
+      for (int it = 0; it < SEGS; ++it) {
+        const int p = prow + it * PER_IT;
+        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        if (oy < a.Ho && ox < a.Wo) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(ldsf + p * OUTF_PITCH + 8 * seg);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(ldsf + p * OUTF_PITCH + 8 * seg + 4);
+          bf16x8 o = *reinterpret_cast<bf16x8*>(&prev[it]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (ok[i]) outp[off[i]] = (__bf16)(acc[mt][j][i] + prev[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (ok[i]) {
-            const float v = acc[mt][j][i];
-            s1[j] += v;
-            s2[j] += v * v;
-            outp[off[i]] = (__bf16)v;
+          for (int k = 0; k < 4; ++k) {
+            o[k] = (__bf16)(lo[k] + (float)o[k]);
+            o[4 + k] = (__bf16)(hi[k] + (float)o[4 + k]);
           }
+          *reinterpret_cast<bf16x8*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) = o;
+        }
       }
     }
   }
@@ -313,7 +312,7 @@ static int bf_validate(const dt_conv_desc* d) {
   DT_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv_bf16: bad sizes");
   DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && (d->stride == 2 || d->stride == 1)),
              "conv_bf16: ksize/stride (%d,%d) unsupported", d->ksize, d->stride);
-  DT_REQUIRE((d->C0 & 7) == 0 && (d->C1 & 7) == 0, "conv_bf16: channels must be multiples of 8");
+  DT_REQUIRE((d->C0 & 7) == 0 && (d->C1 & 7) == 0 && (d->Cout & 7) == 0, "conv_bf16: channels must be multiples of 8");
   DT_REQUIRE(d->C1 == 0 || (d->C0 % BF_CK) == 0, "conv_bf16: concat needs C0 %% 32 == 0");
   DT_REQUIRE(d->mode0 >= 0 && d->mode0 <= 2, "conv_bf16: mode0 %d unsupported", d->mode0);
   DT_REQUIRE(d->mode0 == 0 || ((d->Hin & 1) == 0 && (d->Win & 1) == 0), "conv_bf16: mode0 needs even Hin/Win");
