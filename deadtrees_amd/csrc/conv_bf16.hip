@@ -456,9 +456,32 @@ __global__ __launch_bounds__(256) void bn_act_bf16_kernel(const void* __restrict
                                                           const float* __restrict__ rscale,
                                                           const float* __restrict__ rshift, __bf16* __restrict__ out,
                                                           int64_t n8, int C8, int relu) {
+  // grid stride is a multiple of C8 (host check): one channel group per thread, coefficients loaded once
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-    const int c = (int)(i % C8) * 8;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(i0 % C8) * 8;
+  float sc[8], sf[8], rsc[8], rsf[8];
+  auto ldc8 = [](const float* __restrict__ p, int cc, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + cc), b = *reinterpret_cast<const f32x4*>(p + cc + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = a[k];
+      v[4 + k] = b[k];
+    }
+  };
+  ldc8(scale, c, sc);
+  ldc8(shift, c, sf);
+  if (rscale) {
+    ldc8(rscale, c, rsc);
+    ldc8(rshift, c, rsf);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      rsc[k] = 1.f;
+      rsf[k] = 0.f;
+    }
+  }
+  for (int64_t i = i0; i < n8; i += stride) {
     float v[8];
     if (Y_F32) {
       const f32x4 a = reinterpret_cast<const f32x4*>(y)[2 * i], bq = reinterpret_cast<const f32x4*>(y)[2 * i + 1];
@@ -477,10 +500,10 @@ __global__ __launch_bounds__(256) void bn_act_bf16_kernel(const void* __restrict
     bf16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float f = v[k] * scale[c + k] + shift[c + k];
+      float f = v[k] * sc[k] + sf[k];
       if (res) {
         float rr = (float)rv[k];
-        if (rscale) rr = rr * rscale[c + k] + rshift[c + k];
+        if (rscale) rr = rr * rsc[k] + rsf[k];
         f += rr;
       }
       if (relu) f = f < 0.f ? 0.f : f;
@@ -495,6 +518,9 @@ extern "C" int dt_bn_act_bf16(const void* y, int y_is_f32, const float* scale, c
                               void* stream) {
   DT_REQUIRE(y && scale && shift && out && n_pix > 0 && C > 0 && (C & 7) == 0, "bn_act_bf16: bad args (C%%8)");
   DT_REQUIRE((rscale == nullptr) == (rshift == nullptr), "bn_act_bf16: rscale/rshift must come together");
+  DT_REQUIRE(256 % (C / 8) == 0, "bn_act_bf16: C/8 must divide 256 (C=%d)", C);
+  DT_REQUIRE((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)rscale | (uintptr_t)rshift) & 15) == 0,
+             "bn_act_bf16: per-channel arrays must be 16-byte aligned");
   const int64_t n8 = n_pix * C / 8;
   int64_t g = (n8 + 255) / 256;
   if (g > 4096) g = 4096;

@@ -13,7 +13,26 @@ __device__ __forceinline__ void load8(const bf16x8* p, size_t i, float (&v)[8]) 
   for (int k = 0; k < 8; ++k) v[k] = (float)a[k];
 }
 
+// 8 consecutive per-channel fp32 coefficients (c % 8 == 0) as two 16-byte loads
+__device__ __forceinline__ void ldc8(const float* __restrict__ p, int c, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p + c), b = *reinterpret_cast<const f32x4*>(p + c + 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k] = a[k];
+    v[4 + k] = b[k];
+  }
+}
+
 // ------------------------------------------------------------------ BN backward, pass 1
+// rows (pixels) per workgroup: 256 for small maps, grown so that a launch has at most ~2048 row blocks — the
+// in-workgroup reduction and the second-stage row count then stay small next to the streaming part.
+static inline int64_t bnb16_rb(int64_t n_pix) {
+  int64_t rb = BNB16_RB;
+  const int64_t want = (n_pix + 2047) / 2048;
+  if (want > rb) rb = (want + BNB16_RB - 1) / BNB16_RB * BNB16_RB;
+  return rb;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const bf16x8* __restrict__ dout,
                                                                  const bf16x8* __restrict__ out_act,
                                                                  const bf16x8* __restrict__ y,
@@ -22,29 +41,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const bf16x8* _
                                                                  const float* __restrict__ act_scale,
                                                                  const float* __restrict__ act_shift,
                                                                  float* __restrict__ red, int64_t n_pix, int C8, int Q,
-                                                                 int P) {
-  __shared__ float sh[2][256][9];
+                                                                 int P, int64_t RB) {
+  __shared__ float sh[16][256];   // [sum kind * 8 + k][thread]: conflict-free columns
   const int t = threadIdx.x;
   const int q = t % Q, rl = t / Q, RL = 256 / Q;
   const int cq = blockIdx.x * Q + q;
-  const int64_t p0 = (int64_t)blockIdx.y * BNB16_RB;
-  int64_t p1 = p0 + BNB16_RB;
+  const int64_t p0 = (int64_t)blockIdx.y * RB;
+  int64_t p1 = p0 + RB;
   if (p1 > n_pix) p1 = n_pix;
   float mu[8], is[8], asc[8], ash[8], sg[8], sx[8];
   const bool from_y = out_act == nullptr && act_scale != nullptr;
+  ldc8(mean, cq * 8, mu);
+  ldc8(invstd, cq * 8, is);
+  if (from_y) {
+    ldc8(act_scale, cq * 8, asc);
+    ldc8(act_shift, cq * 8, ash);
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    mu[k] = mean[cq * 8 + k];
-    is[k] = invstd[cq * 8 + k];
-    asc[k] = from_y ? act_scale[cq * 8 + k] : 1.f;
-    ash[k] = from_y ? act_shift[cq * 8 + k] : 0.f;
+    if (!from_y) {
+      asc[k] = 1.f;
+      ash[k] = 0.f;
+    }
     sg[k] = sx[k] = 0.f;
   }
-  for (int64_t p = p0 + rl; p < p1; p += RL) {
-    const size_t o = (size_t)p * C8 + cq;
-    float g[8], yv[8];
-    load8(dout, o, g);
-    load8(y, o, yv);
+  auto masked = [&](float (&g)[8], const float (&yv)[8], size_t o) {
     if (out_act) {
       float a[8];
       load8(out_act, o, a);
@@ -58,6 +79,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const bf16x8* _
         g[k] = a > 0.f ? g[k] : 0.f;
       }
     }
+  };
+  int64_t p = p0 + rl;
+  for (; p + RL < p1; p += 2 * RL) {   // two rows in flight per thread
+    const size_t o0 = (size_t)p * C8 + cq, o1 = (size_t)(p + RL) * C8 + cq;
+    float g0[8], y0[8], g1[8], y1[8];
+    load8(dout, o0, g0);
+    load8(dout, o1, g1);
+    load8(y, o0, y0);
+    load8(y, o1, y1);
+    masked(g0, y0, o0);
+    masked(g1, y1, o1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sg[k] += g0[k];
+      sx[k] += g0[k] * ((y0[k] - mu[k]) * is[k]);
+      sg[k] += g1[k];
+      sx[k] += g1[k] * ((y1[k] - mu[k]) * is[k]);
+    }
+  }
+  for (; p < p1; p += RL) {
+    const size_t o = (size_t)p * C8 + cq;
+    float g[8], yv[8];
+    load8(dout, o, g);
+    load8(y, o, yv);
+    masked(g, yv, o);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       sg[k] += g[k];
@@ -66,37 +112,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const bf16x8* _
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    sh[0][t][k] = sg[k];
-    sh[1][t][k] = sx[k];
+    sh[k][t] = sg[k];
+    sh[8 + k][t] = sx[k];
   }
   __syncthreads();
+  // pairwise tree over the row lanes (thread t = rl * Q + q): fixed order -> deterministic
+  for (int s = RL >> 1; s >= 1; s >>= 1) {
+    if (rl < s) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sh[k][t] += sh[k][t + s * Q];
+    }
+    __syncthreads();
+  }
   if (rl == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float a = 0.f, b = 0.f;
-      for (int i = 0; i < RL; ++i) {
-        a += sh[0][i * Q + q][k];
-        b += sh[1][i * Q + q][k];
-      }
-      red[(size_t)blockIdx.y * C8 * 8 + cq * 8 + k] = a;
-      red[((size_t)P + blockIdx.y) * C8 * 8 + cq * 8 + k] = b;
+      red[(size_t)blockIdx.y * C8 * 8 + cq * 8 + k] = sh[k][t];
+      red[((size_t)P + blockIdx.y) * C8 * 8 + cq * 8 + k] = sh[8 + k][t];
     }
   }
 }
 
-extern "C" int dt_bn_bwd_rows_bf16(int64_t n_pix) { return dt_cdiv(n_pix, BNB16_RB); }
+extern "C" int dt_bn_bwd_rows_bf16(int64_t n_pix) { return dt_cdiv(n_pix, bnb16_rb(n_pix)); }
 
 extern "C" int dt_bn_bwd_reduce_bf16(const void* dout, const void* out_act, const void* y, const float* mean,
                                      const float* invstd, const float* act_scale, const float* act_shift, float* red,
                                      int64_t n_pix, int C, void* stream) {
   DT_REQUIRE(dout && y && mean && invstd && red && n_pix > 0 && C > 0 && (C & 7) == 0, "bn_bwd_reduce_bf16: bad args");
+  DT_REQUIRE((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)act_scale | (uintptr_t)act_shift) & 15) == 0,
+             "bn_bwd_reduce_bf16: per-channel arrays must be 16-byte aligned");
   const int C8 = C / 8;
   int Q = 64;
   while (Q > C8) Q >>= 1;
   DT_REQUIRE(C8 % Q == 0, "bn_bwd_reduce_bf16: C/8 must be a power of two or a multiple of 64 (C=%d)", C);
   const int P = dt_bn_bwd_rows_bf16(n_pix);
   hipLaunchKernelGGL(bn_bwd_reduce_bf16_kernel, dim3(C8 / Q, P), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dout,
-                     (const bf16x8*)out_act, (const bf16x8*)y, mean, invstd, act_scale, act_shift, red, n_pix, C8, Q, P);
+                     (const bf16x8*)out_act, (const bf16x8*)y, mean, invstd, act_scale, act_shift, red, n_pix, C8, Q, P,
+                     bnb16_rb(n_pix));
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -108,9 +160,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, const float* __restrict__ act_scale,
     const float* __restrict__ act_shift, bf16x8* __restrict__ dy, bf16x8* __restrict__ dres, int dres_acc, int64_t n8,
     int C8, float inv_count) {
+  // the grid stride is a multiple of C8 (host check), so a thread stays on ONE channel group: its per-channel
+  // coefficients are loaded once instead of 56 scalar loads per 16-byte element group
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
-    const int c = (int)(i % C8) * 8;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(i0 % C8) * 8;
+  float mu[8], is[8], gi[8], kb[8], kg[8], asc[8], ash[8];
+  {
+    // c is a multiple of 8: two 16-byte loads per coefficient array, all issued before the first use
+    float ga[8], db[8], dg[8];
+    ldc8(mean, c, mu);
+    ldc8(invstd, c, is);
+    ldc8(gamma, c, ga);
+    ldc8(dbeta, c, db);
+    ldc8(dgamma, c, dg);
+    if (act_scale) {
+      ldc8(act_scale, c, asc);
+      ldc8(act_shift, c, ash);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        asc[k] = 1.f;
+        ash[k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      gi[k] = ga[k] * is[k];
+      kb[k] = db[k] * inv_count;
+      kg[k] = dg[k] * inv_count;
+    }
+  }
+  for (int64_t i = i0; i < n8; i += stride) {
     float g[8], yv[8];
     load8(dout, i, g);
     load8(y, i, yv);
@@ -122,7 +203,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(
     } else if (act_scale) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float a = (float)(__bf16)(yv[k] * act_scale[c + k] + act_shift[c + k]);
+        const float a = (float)(__bf16)(yv[k] * asc[k] + ash[k]);
         g[k] = a > 0.f ? g[k] : 0.f;
       }
     }
@@ -142,9 +223,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(
     bf16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float is = invstd[c + k];
-      const float xh = (yv[k] - mean[c + k]) * is;
-      o[k] = (__bf16)(gamma[c + k] * is * (g[k] - dbeta[c + k] * inv_count - xh * (dgamma[c + k] * inv_count)));
+      const float xh = (yv[k] - mu[k]) * is[k];
+      o[k] = (__bf16)(gi[k] * (g[k] - kb[k] - xh * kg[k]));
     }
     dy[i] = o;
   }
@@ -157,6 +237,10 @@ extern "C" int dt_bn_bwd_apply_bf16(const void* dout, const void* out_act, const
   DT_REQUIRE(dout && y && mean && invstd && gamma && red && dgamma && dbeta && dy && n_pix > 0 && C > 0 &&
                  (C & 7) == 0 && P > 0,
              "bn_bwd_apply_bf16: bad args");
+  DT_REQUIRE(256 % (C / 8) == 0, "bn_bwd_apply_bf16: C/8 must divide 256 (C=%d)", C);
+  DT_REQUIRE((((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma | (uintptr_t)dgamma | (uintptr_t)dbeta |
+               (uintptr_t)act_scale | (uintptr_t)act_shift) & 15) == 0,
+             "bn_bwd_apply_bf16: per-channel arrays must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   int rc = dt_bn_bwd_finish_sums(red, P, C, dgamma, dbeta, st);
   if (rc != DT_OK) return rc;

@@ -302,6 +302,76 @@ def confusion_matrix(pred, target, lu=None, K=2, counts=None):
     return counts, err
 
 
+# ---- bf16 elementwise kernels (thin wrappers; the engine calls the C ABI directly with its own buffers)
+def bn_act_bf16(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
+    """bf16 (or fp32) y [.., C] -> bf16 act(y*scale+shift + (res*rscale+rshift))"""
+    _gpu(y, scale, shift, res)
+    Cq = y.shape[-1]
+    out = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+    _lib.check(_lib.load().dt_bn_act_bf16(_p(y), 1 if y.dtype == torch.float32 else 0, _p(scale), _p(shift), _p(res),
+                                          _p(rscale), _p(rshift), _p(out), y.numel() // Cq, Cq, 1 if relu else 0,
+                                          _st()), "dt_bn_act_bf16")
+    return out
+
+
+def bn_backward_bf16(dout, out_act, y, mean, invstd, gamma, want_dres=False, act_scale=None, act_shift=None,
+                     dres=None):
+    """-> (dy bf16, dgamma f32, dbeta f32, dres bf16 or None); same contract as bn_backward, bf16 activations.
+    `dres` given: the masked gradient is ADDED to it (gradient join)."""
+    _gpu(dout, y, mean, invstd, gamma)
+    lib = _lib.load()
+    Cq = y.shape[-1]
+    n_pix = y.numel() // Cq
+    P = lib.dt_bn_bwd_rows_bf16(n_pix)
+    red = torch.empty(lib.dt_bn_stats_floats(P, Cq), dtype=torch.float32, device=y.device)
+    _lib.check(lib.dt_bn_bwd_reduce_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(act_scale),
+                                         _p(act_shift), _p(red), n_pix, Cq, _st()), "dt_bn_bwd_reduce_bf16")
+    dy = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+    dgamma = torch.empty(Cq, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(Cq, dtype=torch.float32, device=y.device)
+    acc = dres is not None
+    if want_dres and dres is None:
+        dres = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+    _lib.check(lib.dt_bn_bwd_apply_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(act_scale),
+                                        _p(act_shift), _p(red), P, _p(dgamma), _p(dbeta), _p(dy), _p(dres),
+                                        1 if acc else 0, n_pix, Cq, _st()), "dt_bn_bwd_apply_bf16")
+    return dy, dgamma, dbeta, dres
+
+
+def maxpool3x3s2_bf16(x):
+    """bf16 NHWC -> (pooled bf16, argmax bytes [B,Ho,Wo,C] uint8: window position kh*3+kw of the first maximum)"""
+    _gpu(x)
+    B, H, W, Cq = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((B, Ho, Wo, Cq), dtype=torch.bfloat16, device=x.device)
+    am = torch.empty((B, Ho, Wo, Cq), dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().dt_maxpool3x3s2_bf16_amax(_p(x), _p(out), _p(am), B, H, W, Cq, _st()),
+               "dt_maxpool3x3s2_bf16_amax")
+    return out, am
+
+
+def maxpool3x3s2_bwd_bf16(dout, argmax, H, W, dx=None):
+    """gradient of maxpool3x3s2_bf16 wrt its [B,H,W,C] input; `dx` given: accumulate into it"""
+    _gpu(dout, argmax)
+    B, _, _, Cq = dout.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty((B, H, W, Cq), dtype=torch.bfloat16, device=dout.device)
+    _lib.check(_lib.load().dt_maxpool3x3s2_bwd_bf16(_p(dout), _p(argmax), _p(dx), 1 if acc else 0, B, H, W, Cq, _st()),
+               "dt_maxpool3x3s2_bwd_bf16")
+    return dx
+
+
+def upsample2x_bwd_bf16(dup):
+    """[B,2H,2W,C] bf16 gradient of a nearest x2 upsample -> [B,H,W,C] (2x2 sums, one rounding)"""
+    _gpu(dup)
+    B, H2, W2, Cq = dup.shape
+    dx = torch.empty((B, H2 // 2, W2 // 2, Cq), dtype=torch.bfloat16, device=dup.device)
+    _lib.check(_lib.load().dt_upsample2x_bwd_bf16(_p(dup), _p(dx), B, H2 // 2, W2 // 2, Cq, _st()),
+               "dt_upsample2x_bwd_bf16")
+    return dx
+
+
 def signed_distmap(labels: torch.Tensor, K: int):
     """int64 labels [B,H,W] -> (fp32 distance maps [B,K,H,W], err flag) — the boundary-loss maps of
     loss/losses.py:159-178 as attached by data/deadtreedata.py:182-185, computed exactly on the device."""

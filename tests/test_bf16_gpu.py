@@ -182,3 +182,91 @@ def test_bf16_training_step_against_fp32_path():
     am_a = m.predict_classes(img, precision="bf16")
     am_b = m.predict_classes(img, precision="fp32")
     assert float((am_a == am_b).float().mean()) > 0.97
+
+
+# ---------------------------------------------------------------- bf16 elementwise kernels, one by one
+def _bf(t):
+    """round to bf16; returns (device bf16 NHWC-as-given tensor, fp64 copy of the rounded values)"""
+    q = t.to(BF)
+    return q.to(DEV), q.double()
+
+
+@pytest.mark.parametrize("n_pix,C", [(2 * 24 * 40, 16), (3 * 64 * 64, 64), (700, 512), (2 * 512 * 300, 32)])
+@pytest.mark.parametrize("mode", ["stored_act", "virtual_act", "linear"])
+def test_bn_backward_bf16(n_pix, C, mode):
+    """dt_bn_bwd_reduce_bf16 / _apply_bf16 against the fp64 batch-norm backward on the same bf16 operands:
+    dgamma/dbeta to fp32-reduction accuracy, dy and the residual gradient to one bf16 rounding."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n_pix % 97 + C)
+    y = torch.randn((n_pix, C), generator=g) * (0.5 + torch.rand(C, generator=g)) + 0.3 * torch.randn(C, generator=g)
+    dout = torch.randn((n_pix, C), generator=g)
+    gamma = 1 + 0.3 * torch.randn(C, generator=g)
+    beta = 0.2 * torch.randn(C, generator=g)
+    yg, y64 = _bf(y)
+    dg, d64 = _bf(dout)
+    mean = y64.mean(0)
+    var = y64.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    sc, sh = gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd
+    act, asc, ash = None, None, None
+    gm = d64
+    if mode != "linear":
+        z = torch.relu((y64.float() * sc.float() + sh.float())).to(BF)   # what the forward stored / consumers saw
+        gm = torch.where(z.double() > 0, d64, torch.zeros_like(d64))
+        if mode == "stored_act":
+            act = z.to(DEV)
+        else:
+            asc, ash = sc.float().to(DEV), sh.float().to(DEV)
+    xh = (y64 - mean) * invstd
+    dbeta = gm.sum(0)
+    dgamma = (gm * xh).sum(0)
+    dy = gamma.double() * invstd * (gm - dbeta / n_pix - xh * dgamma / n_pix)
+    prev = torch.randn((n_pix, C), generator=g).to(BF)
+    got_dy, got_dg, got_db, got_res = ops.bn_backward_bf16(
+        dg, act, yg, mean.float().to(DEV), invstd.float().to(DEV), gamma.to(DEV), act_scale=asc, act_shift=ash,
+        dres=prev.clone().to(DEV))
+    tol = 3e-5 * float(gm.abs().sum(0).max()) + 1e-4
+    assert float((got_db.cpu().double() - dbeta).abs().max()) < tol
+    assert float((got_dg.cpu().double() - dgamma).abs().max()) < 4 * tol
+    close_bf16(got_dy.cpu().double(), dy, extra=1e-4)
+    close_bf16(got_res.cpu().double(), prev.double() + gm)
+
+
+@pytest.mark.parametrize("C", [16, 64, 256])
+def test_bn_act_bf16(C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    y = torch.randn((2, 20, 24, C), generator=g)
+    res = torch.randn((2, 20, 24, C), generator=g)
+    sc, sh = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    rsc, rsh = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    yg, y64 = _bf(y)
+    rg, r64 = _bf(res)
+    want = torch.relu(y64 * sc.double() + sh.double() + r64 * rsc.double() + rsh.double())
+    got = ops.bn_act_bf16(yg, sc.to(DEV), sh.to(DEV), rg, rsc.to(DEV), rsh.to(DEV))
+    close_bf16(got.cpu().double(), want)
+    got32 = ops.bn_act_bf16(y.to(DEV), sc.to(DEV), sh.to(DEV), relu=False)      # fp32 input (stem), no residual
+    close_bf16(got32.cpu().double(), y.double() * sc.double() + sh.double())
+
+
+def test_maxpool_and_upsample_backward_bf16():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 16, 26, 30), generator=g)                  # NCHW reference layout
+    xg = x.to(BF).permute(0, 2, 3, 1).contiguous().to(DEV)
+    x64 = x.to(BF).double().requires_grad_(True)
+    want = F.max_pool2d(x64, 3, 2, 1)
+    pooled, am = ops.maxpool3x3s2_bf16(xg)
+    assert torch.equal(pooled.cpu().permute(0, 3, 1, 2).double(), want.detach())
+    d = torch.randn(want.shape, generator=g).to(BF)
+    want.backward(d.double())
+    dx = ops.maxpool3x3s2_bwd_bf16(d.permute(0, 2, 3, 1).contiguous().to(DEV), am, 26, 30)
+    close_bf16(dx.cpu().permute(0, 3, 1, 2).double(), x64.grad)
+    prev = torch.randn(x.shape, generator=g).to(BF)
+    dx2 = ops.maxpool3x3s2_bwd_bf16(d.permute(0, 2, 3, 1).contiguous().to(DEV), am, 26, 30,
+                                    dx=prev.permute(0, 2, 3, 1).contiguous().to(DEV))
+    close_bf16(dx2.cpu().permute(0, 3, 1, 2).double(), x64.grad + prev.double())
+    up = torch.randn((2, 24, 20, 32), generator=g).to(BF)          # NHWC
+    got = ops.upsample2x_bwd_bf16(up.to(DEV))
+    want_up = up.double().reshape(2, 12, 2, 10, 2, 32).sum(dim=(2, 4))
+    close_bf16(got.cpu().double(), want_up)
