@@ -662,3 +662,61 @@ extern "C" int dt_confusion_matrix(const int64_t* pred_i64, const uint8_t* pred_
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
+
+// ------------------------------------------------------------------ ensemble vote
+// deployment/inference.py:65-116 PyTorchEnsembleInference.run: per-pixel torch.mode over the class maps of an odd
+// number of models.  torch.mode returns the SMALLEST of the most frequent values (checked against torch on the CPU
+// in tests/test_surface_gpu.py); counts live in registers, 4 pixels per lane (one dword per model).
+#define VOTE_MAXK 8
+__global__ __launch_bounds__(256) void ensemble_vote_kernel(const uint32_t* __restrict__ maps, int M, int64_t n4, int K,
+                                                            uint32_t* __restrict__ out_u8, int64_t* __restrict__ out_i64,
+                                                            int32_t* __restrict__ err) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    unsigned cnt[4][VOTE_MAXK];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int k = 0; k < VOTE_MAXK; ++k) cnt[p][k] = 0;
+    bool bad = false;
+    for (int m = 0; m < M; ++m) {
+      const uint32_t v = maps[(size_t)m * n4 + i];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const unsigned c = (v >> (8 * p)) & 0xffu;
+        bad |= c >= (unsigned)K;
+#pragma unroll
+        for (int k = 0; k < VOTE_MAXK; ++k) cnt[p][k] += (c == (unsigned)k) ? 1u : 0u;
+      }
+    }
+    if (bad) err[0] = 1;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned best = 0, bc = cnt[p][0];
+#pragma unroll
+      for (int k = 1; k < VOTE_MAXK; ++k)
+        if (cnt[p][k] > bc) {   // strict: ties keep the smaller class (torch.mode)
+          bc = cnt[p][k];
+          best = k;
+        }
+      packed |= best << (8 * p);
+      if (out_i64) out_i64[4 * i + p] = (int64_t)best;
+    }
+    if (out_u8) out_u8[i] = packed;
+  }
+}
+
+extern "C" int dt_ensemble_vote(const uint8_t* maps, int M, int64_t n, int K, uint8_t* out_u8, int64_t* out_i64,
+                                int32_t* err_flag, void* stream) {
+  DT_REQUIRE(maps && err_flag && (out_u8 || out_i64) && M > 0 && n > 0, "ensemble_vote: bad args");
+  DT_REQUIRE((n & 3) == 0, "ensemble_vote: pixel count must be a multiple of 4 (n=%lld)", (long long)n);
+  DT_REQUIRE(K >= 2 && K <= VOTE_MAXK, "ensemble_vote: K=%d unsupported (2..%d)", K, VOTE_MAXK);
+  const int64_t n4 = n / 4;
+  int64_t g = (n4 + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(ensemble_vote_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)maps,
+                     M, n4, K, (uint32_t*)out_u8, out_i64, err_flag);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

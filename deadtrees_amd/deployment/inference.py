@@ -49,3 +49,37 @@ class PyTorchInference:
         x = ops.normalize_u8(tiles_u8_nhwc.to(device), MEAN, STD, self._channels)   # NHWC f32
         x = x.permute(0, 3, 1, 2).contiguous()
         return self._model.predict_classes(x, dtype="uint8")
+
+
+class PyTorchEnsembleInference:
+    """reference deployment/inference.py:65-116: an odd number of checkpoints, per-pixel majority (torch.mode) of
+    their class maps.  Here every model emits a uint8 map from the fused head kernel and one vote kernel
+    (``dt_ensemble_vote``, ties -> smallest class like torch.mode) replaces stack + mode."""
+
+    def __init__(self, *model_files: Union[str, Path]):
+        self._models, self._channels, self._classes = [], None, None
+        if len(model_files) % 2 == 0:
+            raise ValueError("PyTorchEnsembleInference requires an uneven number of models")
+        for model_file in model_files:
+            model_file = Path(model_file)
+            if model_file.suffix != ".ckpt":
+                raise ValueError(f"Ckpt file expected, but {model_file.suffix} received")
+            model = SemSegment.load_from_checkpoint(model_file)
+            model.eval()
+            if not self._channels:
+                self._channels, self._classes = model.in_channels, model.model.spec.classes
+            if model.in_channels != self._channels or model.model.spec.classes != self._classes:
+                raise ValueError("Models are not compatible since they were trained for different channel configs")
+            self._models.append(model.model)
+
+    def run(self, input_tensor, device: str = "cuda"):
+        if not isinstance(input_tensor, torch.Tensor):
+            raise TypeError("No PyTorch tensor provided")
+        if input_tensor.dim() == 3:
+            input_tensor = input_tensor.unsqueeze(0)
+        if self._channels == 3 and input_tensor.shape[1] == 4:
+            input_tensor = input_tensor[:, 0:3, :, :]     # rgb model but rgbn data
+        x = input_tensor.to(device).contiguous()
+        maps = torch.stack([m.to(device).predict_classes(x, dtype="uint8") for m in self._models], dim=0)
+        out, _ = ops.ensemble_vote(maps, self._classes, dtype="int64")
+        return out.squeeze()

@@ -372,6 +372,22 @@ def upsample2x_bwd_bf16(dup):
     return dx
 
 
+def ensemble_vote(maps_u8: torch.Tensor, K: int, dtype: str = "int64"):
+    """uint8 class maps [M, ...] of M models -> per-pixel mode [...] (ties -> smallest class, torch.mode);
+    returns (map, err flag).  deployment/inference.py:65-116."""
+    _gpu(maps_u8)
+    if maps_u8.dtype != torch.uint8:
+        raise RuntimeError("ensemble_vote: class maps must be uint8")
+    M = maps_u8.shape[0]
+    n = maps_u8[0].numel()
+    out8 = torch.empty(maps_u8.shape[1:], dtype=torch.uint8, device=maps_u8.device) if dtype == "uint8" else None
+    out64 = torch.empty(maps_u8.shape[1:], dtype=torch.int64, device=maps_u8.device) if dtype == "int64" else None
+    err = torch.zeros(1, dtype=torch.int32, device=maps_u8.device)
+    _lib.check(_lib.load().dt_ensemble_vote(_p(maps_u8.contiguous()), M, n, K, _p(out8), _p(out64), _p(err), _st()),
+               "dt_ensemble_vote")
+    return (out64 if out64 is not None else out8), err
+
+
 def signed_distmap(labels: torch.Tensor, K: int):
     """int64 labels [B,H,W] -> (fp32 distance maps [B,K,H,W], err flag) — the boundary-loss maps of
     loss/losses.py:159-178 as attached by data/deadtreedata.py:182-185, computed exactly on the device."""

@@ -190,6 +190,12 @@ int dt_gwdice_posgrad(const int64_t* labels, const float* sample_coef, float* po
 int dt_confusion_matrix(const int64_t* pred_i64, const uint8_t* pred_u8, const int64_t* target, const int64_t* lu,
                         int K, int64_t n, int64_t* counts, int32_t* err_flag, void* stream);
 
+/* Ensemble vote (deployment/inference.py:65-116 PyTorchEnsembleInference.run): per-pixel torch.mode over the
+ * uint8 class maps of M models, maps[M][n]; ties -> the smallest class (torch.mode).  n % 4 == 0, 2 <= K <= 8.
+ * Writes uint8 and/or int64 maps (either pointer may be NULL); classes >= K set err_flag[0]. */
+int dt_ensemble_vote(const uint8_t* maps, int M, int64_t n, int K, uint8_t* out_u8, int64_t* out_i64,
+                     int32_t* err_flag, void* stream);
+
 /* Signed Euclidean distance maps of the boundary loss, computed on the device in place of the
  * loader's scipy pass: data/deadtreedata.py:182-185 -> loss/losses.py:159-178 one_hot2dist(resolution=[1,1]).
  * labels int64 [B,H,W] -> dist fp32 [B,K,H,W]; per class: floor(edt to the class) outside it, 1 - floor(edt to the
