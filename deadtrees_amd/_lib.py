@@ -67,6 +67,9 @@ SIGNATURES = {
     "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_confusion_matrix": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, I64, c_f, c_f, c_f]),
+    "dt_augment_normalize_u8": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float), c_f]),
+    "dt_augment_labels": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_ensemble_vote": (C.c_int, [c_f, C.c_int, I64, C.c_int, c_f, c_f, c_f, c_f]),
     "dt_signed_distmap_workspace": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "dt_signed_distmap": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

@@ -587,3 +587,117 @@ extern "C" int dt_normalize_u8(const uint8_t* src, float* dst, int64_t n_pix, in
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
+
+// ------------------------------------------------------------------ training augmentation on the device
+// data/deadtreedata.py:128-146 `train_transform`: OneOf(HorizontalFlip, VerticalFlip) -> RandomRotate90 ->
+// RandomBrightnessContrast(brightness_by_max=False) -> Normalize -> ToTensorV2, per sample on loader CPUs.
+// Here: the host draws the per-sample parameters, one gather pass applies flip + rot90 + the brightness/contrast
+// LUT + normalisation while converting uint8 NHWC tiles to the fp32 NHWC stem input; labels take the same
+// geometric map.  geo[b] = (flip: 0 none, 1 horizontal, 2 vertical; rot: k of np.rot90, counter-clockwise).
+__device__ __forceinline__ void aug_source_pixel(int flip, int rot, int y, int x, int H, int W, int* sy, int* sx) {
+  // out = rot90^k(flip(in)):  rot90(m,1)[i][j] = m[j][N-1-i]
+  int ry = y, rx = x;
+  if (rot == 1) { ry = x; rx = W - 1 - y; }
+  else if (rot == 2) { ry = H - 1 - y; rx = W - 1 - x; }
+  else if (rot == 3) { ry = H - 1 - x; rx = y; }
+  if (flip == 1) rx = W - 1 - rx;
+  else if (flip == 2) ry = H - 1 - ry;
+  *sy = ry;
+  *sx = rx;
+}
+
+__global__ __launch_bounds__(256) void u8_image_sums_kernel(const uint8_t* __restrict__ src, int64_t n_per,
+                                                            unsigned long long* __restrict__ sums) {
+  const int b = blockIdx.y;
+  const uint8_t* p = src + (size_t)b * n_per;
+  unsigned long long s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_per; i += (int64_t)gridDim.x * 256) s += p[i];
+  double d = wave_sum_d((double)s);   // < 2^53: exact
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&sums[b], (unsigned long long)(sh[0] + sh[1] + sh[2] + sh[3]));  // integer: exact
+}
+
+__global__ __launch_bounds__(256) void augment_normalize_u8_kernel(const uint8_t* __restrict__ src,
+                                                                   float* __restrict__ dst,
+                                                                   const int32_t* __restrict__ geo,
+                                                                   const float* __restrict__ bc,
+                                                                   const unsigned long long* __restrict__ sums, int H,
+                                                                   int W, int Cs, int Cd, f32x4 mean, f32x4 stdv) {
+  const int b = blockIdx.y;
+  const int flip = geo[2 * b], rot = geo[2 * b + 1];
+  const float alpha = bc[2 * b], beta = bc[2 * b + 1];
+  // RandomBrightnessContrast on uint8 (brightness_by_max=False): lut(v) = uint8(clip(v*alpha + beta*mean(img), 0, 255))
+  const float add = beta == 0.f ? 0.f : (float)((double)beta * ((double)sums[b] / ((double)H * W * Cs)));
+  const int64_t n_pix = (int64_t)H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pix; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    int sy, sx;
+    aug_source_pixel(flip, rot, y, x, H, W, &sy, &sx);
+    const uint8_t* sp = src + (((size_t)b * H + sy) * W + sx) * Cs;
+    float* dp = dst + ((size_t)b * n_pix + i) * Cd;
+    for (int c = 0; c < Cd; ++c) {
+      float v = (float)sp[c];
+      if (alpha != 1.f || beta != 0.f) {
+        v = v * alpha + add;
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+        v = floorf(v);
+      }
+      dp[c] = (v - mean[c] * 255.f) * (1.f / (stdv[c] * 255.f));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void augment_labels_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst,
+                                                             const int32_t* __restrict__ geo, int H, int W) {
+  const int b = blockIdx.y;
+  const int flip = geo[2 * b], rot = geo[2 * b + 1];
+  const int64_t n_pix = (int64_t)H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pix; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    int sy, sx;
+    aug_source_pixel(flip, rot, y, x, H, W, &sy, &sx);
+    dst[(size_t)b * n_pix + i] = src[((size_t)b * H + sy) * W + sx];
+  }
+}
+
+extern "C" int dt_augment_normalize_u8(const uint8_t* src, float* dst, const int32_t* geo, const float* bc,
+                                       uint64_t* sums_scratch, int B, int H, int W, int Csrc, int Cdst,
+                                       const float* mean, const float* stdv, void* stream) {
+  DT_REQUIRE(src && dst && geo && bc && sums_scratch && mean && stdv && B > 0 && H > 0 && W > 0 && Cdst > 0 &&
+                 Cdst <= 4 && Cdst <= Csrc,
+             "augment_normalize_u8: bad args");
+  DT_REQUIRE(B <= 65535, "augment_normalize_u8: B must be <= 65535");
+  f32x4 m = {0, 0, 0, 0}, s = {1, 1, 1, 1};
+  for (int c = 0; c < Cdst; ++c) {
+    m[c] = mean[c];
+    s[c] = stdv[c];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sums_scratch, 0, (size_t)B * sizeof(uint64_t), st) != hipSuccess) {
+    dt_set_error("augment_normalize_u8: memset failed");
+    return DT_EHIP;
+  }
+  const int64_t n_per = (int64_t)H * W * Csrc;
+  int gx = dt_cdiv(n_per, 256 * 16);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(u8_image_sums_kernel, dim3(gx, B), dim3(256), 0, st, src, n_per, (unsigned long long*)sums_scratch);
+  DT_LAUNCH_CHECK();
+  int gp = dt_cdiv((int64_t)H * W, 256);
+  if (gp > 1024) gp = 1024;
+  hipLaunchKernelGGL(augment_normalize_u8_kernel, dim3(gp, B), dim3(256), 0, st, src, dst, geo, bc,
+                     (const unsigned long long*)sums_scratch, H, W, Csrc, Cdst, m, s);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+extern "C" int dt_augment_labels(const int64_t* src, int64_t* dst, const int32_t* geo, int B, int H, int W,
+                                 void* stream) {
+  DT_REQUIRE(src && dst && geo && B > 0 && B <= 65535 && H > 0 && W > 0, "augment_labels: bad args");
+  int gp = dt_cdiv((int64_t)H * W, 256);
+  if (gp > 1024) gp = 1024;
+  hipLaunchKernelGGL(augment_labels_kernel, dim3(gp, B), dim3(256), 0, (hipStream_t)stream, src, dst, geo, H, W);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

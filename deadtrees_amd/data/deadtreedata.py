@@ -38,6 +38,38 @@ def val_transform(image: np.ndarray, mask: Optional[np.ndarray] = None):
     return out
 
 
+def draw_train_params(batch: int, rng: np.random.Generator):
+    """Per-sample random parameters of the reference's ``train_transform`` (deadtreedata.py:128-146):
+    OneOf([HorizontalFlip, VerticalFlip], p=0.5) -> 25 % each; RandomRotate90(p=0.5) -> k = randint(0, 3);
+    RandomBrightnessContrast(p=0.5, brightness_limit=0.2, contrast_limit=0.15): alpha = 1 + U(-.15, .15),
+    beta = U(-.2, .2).  Returns (geo int32 [B,2], bc float32 [B,2]) for ``train_transform_device``."""
+    geo = np.zeros((batch, 2), np.int32)
+    bc = np.tile(np.array([1.0, 0.0], np.float32), (batch, 1))
+    for b in range(batch):
+        if rng.random() < 0.5:
+            geo[b, 0] = 1 if rng.random() < 0.5 else 2
+        if rng.random() < 0.5:
+            geo[b, 1] = int(rng.integers(0, 4))
+        if rng.random() < 0.5:
+            bc[b] = (1.0 + rng.uniform(-0.15, 0.15), rng.uniform(-0.2, 0.2))
+    return torch.from_numpy(geo), torch.from_numpy(bc)
+
+
+def train_transform_device(tiles_u8_nhwc: torch.Tensor, mask: torch.Tensor, lu: Optional[torch.Tensor],
+                           rng: np.random.Generator, in_channels: int = 3):
+    """``train_transform`` + ``transform`` (deadtreedata.py:128-146,165-176) for a whole batch already in HBM:
+    uint8 [B,H,W,4] tiles, int64 masks (and land-use maps) -> (NCHW fp32 image batch, mask, lu) with ONE fused
+    flip/rot90/brightness-contrast/normalise pass and one gather per label map (kernels `dt_augment_*`)."""
+    from .. import ops
+    B = tiles_u8_nhwc.shape[0]
+    geo, bc = draw_train_params(B, rng)
+    geo, bc = geo.to(tiles_u8_nhwc.device), bc.to(tiles_u8_nhwc.device)
+    img = ops.augment_normalize_u8(tiles_u8_nhwc, geo, bc, MEAN, STD, in_channels).permute(0, 3, 1, 2)
+    mask = ops.augment_labels(mask.long(), geo)
+    lu = ops.augment_labels(lu.long(), geo) if lu is not None else None
+    return img, mask, lu
+
+
 class _SyntheticLoader:
     def __init__(self, n_batches, batch_size, size, in_channels, classes, seed, wrap_main, device, with_distmap):
         self.n, self.bs, self.size, self.c, self.k = n_batches, batch_size, size, in_channels, classes

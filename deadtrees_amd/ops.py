@@ -372,6 +372,37 @@ def upsample2x_bwd_bf16(dup):
     return dx
 
 
+def augment_normalize_u8(src_u8_nhwc, geo, bc, mean, std, c_dst):
+    """uint8 [B,H,W,Csrc] -> fp32 [B,H,W,c_dst]: flip / rot90 / brightness-contrast LUT / normalise in one pass
+    (data/deadtreedata.py:128-146).  geo int32 [B,2] = (flip, rot k), bc fp32 [B,2] = (alpha, beta)."""
+    _gpu(src_u8_nhwc, geo, bc)
+    B, H, W, cs = src_u8_nhwc.shape
+    if geo.dtype != torch.int32 or bc.dtype != torch.float32 or tuple(geo.shape) != (B, 2) or tuple(bc.shape) != (B, 2):
+        raise RuntimeError("augment_normalize_u8: geo must be int32 [B,2] and bc float32 [B,2]")
+    if H != W and bool((geo[:, 1] % 2 == 1).any()):
+        raise RuntimeError("augment_normalize_u8: odd rot90 counts need square tiles")
+    out = torch.empty((B, H, W, c_dst), dtype=torch.float32, device=src_u8_nhwc.device)
+    sums = torch.empty(B, dtype=torch.int64, device=src_u8_nhwc.device)
+    m = (C.c_float * c_dst)(*[float(v) for v in mean[:c_dst]])
+    s = (C.c_float * c_dst)(*[float(v) for v in std[:c_dst]])
+    _lib.check(_lib.load().dt_augment_normalize_u8(_p(src_u8_nhwc.contiguous()), _p(out), _p(geo.contiguous()),
+                                                   _p(bc.contiguous()), _p(sums), B, H, W, cs, c_dst, m, s, _st()),
+               "dt_augment_normalize_u8")
+    return out
+
+
+def augment_labels(labels, geo):
+    """int64 [B,H,W] masks / land-use maps through the same flip + rot90 as the image batch"""
+    _gpu(labels, geo)
+    if labels.dtype != torch.int64 or labels.dim() != 3:
+        raise RuntimeError("augment_labels: labels must be int64 [B,H,W]")
+    B, H, W = labels.shape
+    out = torch.empty_like(labels)
+    _lib.check(_lib.load().dt_augment_labels(_p(labels.contiguous()), _p(out), _p(geo.contiguous()), B, H, W, _st()),
+               "dt_augment_labels")
+    return out
+
+
 def ensemble_vote(maps_u8: torch.Tensor, K: int, dtype: str = "int64"):
     """uint8 class maps [M, ...] of M models -> per-pixel mode [...] (ties -> smallest class, torch.mode);
     returns (map, err flag).  deployment/inference.py:65-116."""

@@ -135,6 +135,18 @@ int dt_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, vo
 int dt_normalize_u8(const uint8_t* src, float* dst, int64_t n_pix, int Csrc, int Cdst, const float* mean,
                     const float* std, void* stream);
 
+/* Training augmentation on the device, data/deadtreedata.py:128-146 `train_transform`:
+ * OneOf(HorizontalFlip, VerticalFlip), RandomRotate90, RandomBrightnessContrast(brightness_by_max=False),
+ * Normalize, ToTensorV2 in ONE gather pass uint8 NHWC [B,H,W,Csrc] -> fp32 NHWC [B,H,W,Cdst].
+ * The host draws the per-sample parameters: geo int32 [B][2] = (flip 0 none / 1 horizontal / 2 vertical,
+ * rot k = np.rot90 count, H == W when k is odd), bc fp32 [B][2] = (alpha, beta); (1, 0) leaves the pixel values
+ * unchanged, else lut(v) = uint8(clip(v*alpha + beta*mean(image), 0, 255)) as albumentations does for uint8.
+ * sums_scratch: B uint64 (per-image pixel sums for the mean).  mean/std: HOST arrays of Cdst floats.
+ * dt_augment_labels applies the same geometric map to int64 [B,H,W] masks / land-use maps. */
+int dt_augment_normalize_u8(const uint8_t* src, float* dst, const int32_t* geo, const float* bc, uint64_t* sums_scratch,
+                            int B, int H, int W, int Csrc, int Cdst, const float* mean, const float* std, void* stream);
+int dt_augment_labels(const int64_t* src, int64_t* dst, const int32_t* geo, int B, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------ segmentation head (K11,K12,K19) */
 /* logits[B,K,H,W] (NCHW) = conv3x3(x[B,H,W,Cin], w[K][3][3][Cin]) + bias; optional uint8/int64 argmax
  * class map (ties -> lowest index, torch.argmax) — smp SegmentationHead + inference.py:62. */

@@ -12,6 +12,10 @@ Pinning status:
     ``deadtrees.loss`` and ``deadtrees.utils.data_handling`` from
     /root/reference and writes ``tests/golden/*.npz``) and against the
     reference's known-answer test (tests/test_tiler.py:56-77).
+  * GWDICE (loss/gwdl.py) values and gradients: pinned the same way (golden vectors from the imported reference).
+  * training augmentation (``augment_ref.py``): geometric steps are the numpy calls albumentations uses; the
+    brightness/contrast LUT is restated from albumentations' published algorithm -> PARITY UNPINNED for that step
+    (albumentations is not installed).  Ensemble vote: checked against ``torch.mode`` itself.
   * network (smp ``Unet`` + ``resnet34``): the arithmetic lives in the
     un-vendored third-party package ``segmentation_models_pytorch>=0.2.1``
     (reference setup.py:47) which is absent here -> PARITY UNPINNED for the

@@ -195,3 +195,51 @@ def test_ensemble_vote_matches_torch_mode(tmp_path):
     ens = PyTorchEnsembleInference(*files).run(x, device=DEV).cpu()
     singles = torch.stack([PyTorchInference(f).run(x, device=DEV).cpu() for f in files], dim=1)
     assert torch.equal(ens, torch.mode(singles, dim=1)[0])          # the reference's stack(dim=1) + mode(axis=1)
+
+
+def test_device_train_transform_matches_numpy_restatement():
+    """dt_augment_normalize_u8 / dt_augment_labels against oracle/augment_ref.py for every flip x rot90 combination
+    (exact: index maps) and brightness/contrast draws (exact LUT incl. clipping; albumentations itself is absent:
+    parity unpinned for that step, see the oracle's header)."""
+    from deadtrees_amd import ops
+    from deadtrees_amd.data.deadtreedata import draw_train_params, train_transform_device
+    from deadtrees_amd.data.synthetic import MEAN, STD
+    from oracle import augment_ref as A
+    rng = np.random.default_rng(3)
+    combos = [(f, r) for f in (0, 1, 2) for r in (0, 1, 2, 3)]
+    B, S = len(combos), 64
+    tiles = rng.integers(0, 256, (B, S, S, 4), dtype=np.uint8)
+    tiles[1] = np.clip(tiles[1].astype(np.int32) + 150, 0, 255)          # drive the LUT into the upper clip
+    mask = rng.integers(0, 3, (B, S, S)).astype(np.int64)
+    geo = torch.tensor(combos, dtype=torch.int32)
+    bc = torch.tensor([[1.0, 0.0] if i % 3 == 0 else [1 + rng.uniform(-.15, .15), rng.uniform(-.2, .2)]
+                       for i in range(B)], dtype=torch.float32)
+    got = ops.augment_normalize_u8(torch.from_numpy(tiles).to(DEV), geo.to(DEV), bc.to(DEV), MEAN, STD, 3).cpu().numpy()
+    gm = ops.augment_labels(torch.from_numpy(mask).to(DEV), geo.to(DEV)).cpu().numpy()
+    for b, (f, r) in enumerate(combos):
+        want = A.train_transform(tiles[b], f, r, float(bc[b, 0]), float(bc[b, 1]), MEAN, STD, 3)
+        if float(bc[b, 0]) == 1.0 and float(bc[b, 1]) == 0.0:
+            np.testing.assert_array_equal(got[b], want)
+        else:   # LUT entries that land within float rounding of an integer may truncate differently: <= 1 grey level
+            diff = np.abs(got[b] - want) * (np.asarray(STD[:3], np.float32) * 255.0)
+            assert float(diff.max()) <= 1.0 + 1e-3 and float((diff > 1e-3).mean()) < 1e-2
+        np.testing.assert_array_equal(gm[b], A.geometric(mask[b], f, r))
+    # non-square tiles: flips and 180-degree turns only
+    t2 = rng.integers(0, 256, (2, 32, 48, 4), dtype=np.uint8)
+    g2 = torch.tensor([[1, 2], [2, 0]], dtype=torch.int32)
+    b2 = torch.tensor([[1.0, 0.0], [1.0, 0.0]])
+    got2 = ops.augment_normalize_u8(torch.from_numpy(t2).to(DEV), g2.to(DEV), b2.to(DEV), MEAN, STD, 4).cpu().numpy()
+    for b in range(2):
+        np.testing.assert_array_equal(got2[b], A.train_transform(t2[b], int(g2[b, 0]), int(g2[b, 1]), 1.0, 0.0, MEAN, STD, 4))
+    with pytest.raises(RuntimeError):
+        ops.augment_normalize_u8(torch.from_numpy(t2).to(DEV), torch.tensor([[0, 1], [0, 0]], dtype=torch.int32).to(DEV),
+                                 b2.to(DEV), MEAN, STD, 4)
+    # batch-level wrapper: shapes / dtypes of the reference's transform() output, distribution of the draws
+    img, m, lu = train_transform_device(torch.from_numpy(tiles).to(DEV), torch.from_numpy(mask).to(DEV), None,
+                                        np.random.default_rng(0), in_channels=3)
+    assert tuple(img.shape) == (B, 3, S, S) and img.dtype == torch.float32 and m.dtype == torch.int64 and lu is None
+    geo_d, bc_d = draw_train_params(4000, np.random.default_rng(1))
+    assert abs(float((geo_d[:, 0] == 0).float().mean()) - 0.5) < 0.03
+    assert abs(float((geo_d[:, 0] == 1).float().mean()) - 0.25) < 0.03
+    assert abs(float((geo_d[:, 1] == 0).float().mean()) - 0.625) < 0.03      # p=0.5 none + 1/4 of the applied draws
+    assert abs(float((bc_d[:, 0] != 1).float().mean()) - 0.5) < 0.03
