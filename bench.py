@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the whole training step as one HIP graph (auto: single-GPU bf16, where the step "
+                         "is shorter than the Python launch path; never with --gpus > 1)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE configs[1] (headline); bf16 = configs[2] (bf16 storage, fp32 accumulate)")
@@ -82,8 +85,9 @@ def main():
     model.to(dev)
     if args.mode == "infer":
         return infer_bench(args, model, dev, world, rank, distributed)
+    use_graph = (not distributed) and (args.graph == "on" or (args.graph == "auto" and args.precision == "bf16"))
     tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed,
-                    precision=args.precision)
+                    precision=args.precision, graph=use_graph)
     tr.broadcast_parameters(0)
     img, mask = synth_batch(B, S, S, 3, 2, seed=1234 + rank)
     img, mask = img.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
@@ -94,11 +98,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_graph:            # set-up, not warm-up: two eager steps, then the capture (first graph call)
+        for _ in range(3):
+            tr.step(img, mask)
     for _ in range(args.warmup):
         tr.step(img, mask)
     sync()
     prof = []
-    model.engine.profile = prof
+    model.engine.profile = None if use_graph else prof   # graph replays run no Python hooks: see below
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -112,11 +119,22 @@ def main():
     if distributed:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt)
+    if use_graph:
+        # per-kernel events for the roofline block come from two EAGER steps after the timed region (same kernels,
+        # same shapes; the timed steps above were graph replays)
+        tr.use_graph = False
+        model.engine.profile = prof
+        for _ in range(2):
+            tr.step(img, mask)
+        torch.cuda.synchronize()
+        model.engine.profile = None
     tiles = B * world * args.steps
     value = tiles / wall
     ms_per_step = 1e3 * wall / args.steps
 
     # ---- roofline of the dominant conv kernel (rank 0's launches)
+    prof_steps = 2 if use_graph else args.steps
+    step_s = float(e0.elapsed_time(e1)) * 1e-3 / args.steps
     agg = {}
     for name, flops, a, b, nbytes in prof:
         t = a.elapsed_time(b) * 1e-3
@@ -136,7 +154,7 @@ def main():
                 "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
                 "algorithmic_bytes_per_launch": round(nb / n), "algorithmic_flops_per_launch": round(fl / n),
                 "hbm_GBps_algorithmic": round(nb / t / 1e9, 1),
-                "share_of_step": round(t / (float(e0.elapsed_time(e1)) * 1e-3), 4)}
+                "share_of_step": round((t / prof_steps) / step_s, 4)}
         # HBM bytes per launch from the PMC passes (profiles/traffic.json: FETCH_SIZE x2 correction for wide
         # coalesced reads on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs of this command)
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -157,11 +175,11 @@ def main():
                                f": reference U-Net (smp Unet/resnet34 topology) {args.precision} train step, "
                                f"batch {B}/GPU, {S}x{S}x3 tiles, GDICE+FOCAL, clip 0.5, Adam 3e-4",
                    "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
-        "loss": round(float(loss), 6),
+        "loss": round(float(loss), 6), "hip_graph": use_graph,
         "whole_net": {"tflops": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12, 2),
                       "mfma_frac": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12 / peak_tf, 4),
                       "hbm_frac_step": round(per_gpu_tiles_s * bytes_per_tile / 1e9 / PEAK_HBM_GBS, 4),
-                      "conv_fwd_dgrad_share_of_step": round(conv_time / (float(e0.elapsed_time(e1)) * 1e-3), 4)},
+                      "conv_fwd_dgrad_share_of_step": round((conv_time / prof_steps) / step_s, 4)},
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -93,8 +93,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float lr, float b1, float b2, float eps, float bc1, float bc2,
                                                    const float* __restrict__ clipcoef,
-                                                   const int32_t* __restrict__ skip) {
+                                                   const int32_t* __restrict__ skip,
+                                                   const float* __restrict__ hyper) {
   if (skip && skip[0] != 0) return;
+  if (hyper) {   // per-step scalars read from the device: a captured HIP graph replays with fresh values
+    lr = hyper[0];
+    bc1 = hyper[1];
+    bc2 = hyper[2];
+  }
   const float cc = clipcoef ? clipcoef[0] : 1.f;
   const float step = lr / bc1;
   const float rs2 = 1.f / sqrtf(bc2);
@@ -139,7 +145,22 @@ extern "C" int dt_adam_step(float* p, const float* g, float* m, float* v, int64_
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, bias_c1, bias_c2, clipcoef, skip_flag);
+                     beta2, eps, bias_c1, bias_c2, clipcoef, skip_flag, (const float*)nullptr);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+extern "C" int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                float beta1, float beta2, float eps, const float* clipcoef, const int32_t* skip_flag,
+                                void* stream) {
+  DT_REQUIRE(p && g && m && v && hyper && n > 0, "adam_dev: bad args");
+  DT_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
+             "adam_dev: buffers must be 16-byte aligned");
+  int64_t grid = ((n >> 2) + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
+                     beta2, eps, 1.f, 1.f, clipcoef, skip_flag, hyper);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

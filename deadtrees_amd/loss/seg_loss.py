@@ -96,7 +96,7 @@ class _SegLoss(torch.autograd.Function):
         if dice_kind == "GWDICE":
             # gwdl.py:110-138 (weighting_mode "default": alpha = 0 for background, 1 otherwise; mean over samples)
             al = torch.ones(K, dtype=torch.float64, device=dev)
-            al[0] = 0.0
+            al[0:1].fill_(0.0)     # fill_: the scalar travels as a kernel argument (HIP-graph capturable)
             gtp = (al[None, :] * vs).sum(1)      # sum_s alpha_i(s) * sum_j (1 - wass_j(s)): the reference's broadcast
             ae = ws.sum(1)
             den = 2.0 * gtp + ae + GW_EPS
@@ -129,14 +129,14 @@ class _SegLoss(torch.autograd.Function):
             wa = alpha if "BOUNDARY-RAMPED" in losses else 1.0
             total = total + wa * parts["boundary_loss"]
             wbound = torch.full((K,), wa * scale, dtype=torch.float32, device=dev)
-            wbound[0] = 0.0
+            wbound[0:1].fill_(0.0)
         wf = torch.zeros(2, dtype=torch.float32, device=dev)
-        wf[1] = gamma
+        wf[1:2].fill_(gamma)
         if "FOCAL" in losses:
             M = cnt.sum() + EPS
             parts["focal_loss"] = -foc.sum() / M
             total = total + parts["focal_loss"]
-            wf[0] = (1.0 / M).float()
+            wf[0:1].copy_((1.0 / M).float().reshape(1))
         parts["ce_loss"] = -ce.sum() / (cnt.sum() + EPS)  # losses.py:187-196 (not part of total)
         # smp Fscore (threshold 0.5, beta 1, eps 1e-7): ignore_channels=[0] and all channels
         def fscore(sl):

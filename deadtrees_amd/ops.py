@@ -452,16 +452,27 @@ class FlatAdam:
         self.norm = torch.zeros(1, dtype=torch.float32, device=params.device)
         self.coef = torch.ones(1, dtype=torch.float32, device=params.device)
 
+    def hyper_values(self, lr: Optional[float] = None):
+        """(lr, 1 - beta1^t, 1 - beta2^t) for the CURRENT step count: what `dt_adam_step_dev` reads from the device"""
+        b1, b2 = self.betas
+        return [float(self.lr if lr is None else lr), 1.0 - b1 ** self.t, 1.0 - b2 ** self.t]
+
     def step(self, grads: torch.Tensor, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None,
-             lr: Optional[float] = None):
+             lr: Optional[float] = None, hyper: Optional[torch.Tensor] = None):
+        """`hyper` (device fp32 [3], see hyper_values) makes the launch sequence independent of the step count, as
+        HIP-graph capture needs; the caller then advances `self.t` and refreshes `hyper` before every replay."""
         lib = _lib.load()
         n = self.p.numel()
         st = _st()
-        self.t += 1
         _lib.check(lib.dt_sumsq(_p(grads), n, _p(self.partial), st), "dt_sumsq")
         _lib.check(lib.dt_clip_coef(_p(self.partial), self.rows, float(self.max_norm or 0.0), float(grad_scale),
                                     _p(self.norm), _p(self.coef), st), "dt_clip_coef")
         b1, b2 = self.betas
+        if hyper is not None:
+            _lib.check(lib.dt_adam_step_dev(_p(self.p), _p(grads), _p(self.m), _p(self.v), n, _p(hyper), b1, b2,
+                                            self.eps, _p(self.coef), _p(skip_flag), st), "dt_adam_step_dev")
+            return self.norm
+        self.t += 1
         _lib.check(lib.dt_adam_step(_p(self.p), _p(grads), _p(self.m), _p(self.v), n,
                                     float(self.lr if lr is None else lr), b1, b2, self.eps, 1.0 - b1 ** self.t,
                                     1.0 - b2 ** self.t, _p(self.coef), _p(skip_flag), st), "dt_adam_step")

@@ -49,7 +49,10 @@ class GradReducer:
 class HipTrainer:
     def __init__(self, model: UNetHIP, lr: float = 3e-4, clip: float = 0.5,
                  losses: Sequence[str] = ("GDICE", "FOCAL"), distributed: bool = False, group=None,
-                 precision: str = "fp32"):
+                 precision: str = "fp32", graph: bool = False):
+        """graph=True: after two eager steps the whole step (forward, loss, backward, clip, Adam) is captured into a
+        HIP graph and replayed — ~750 kernel launches become one, which matters once the bf16 step is shorter than
+        the Python launch path.  Single-GPU only (the gradient all-reduce hook stays eager)."""
         if not model.flat_params.is_cuda:
             raise RuntimeError("HipTrainer needs the model on an MI355X (model.to('cuda'))")
         self.model = model
@@ -65,6 +68,10 @@ class HipTrainer:
             self.reducer.attach(model._grad_buffer())
             model.engine.grad_hook = self.reducer.hook
         self.last = {}
+        if graph and distributed:
+            raise ValueError("graph=True is a single-GPU mode; the bucketed all-reduce path launches eagerly")
+        self.use_graph = bool(graph)
+        self._graph = None
 
     @torch.no_grad()
     def broadcast_parameters(self, src: int = 0):
@@ -75,6 +82,59 @@ class HipTrainer:
     def step(self, img: torch.Tensor, mask: torch.Tensor, distmap: Optional[torch.Tensor] = None,
              alpha: float = 1.0):
         """returns the (device) loss tensor; no host synchronisation happens here."""
+        if self.use_graph:
+            return self._graph_step(img, mask, distmap, alpha)
+        return self._eager_step(img, mask, distmap, alpha)
+
+    # ------------------------------------------------------------------ HIP-graph replay of the whole step
+    def _graph_step(self, img, mask, distmap, alpha):
+        key = (tuple(img.shape), img.dtype, tuple(mask.shape), mask.dtype,
+               None if distmap is None else tuple(distmap.shape), float(alpha))
+        g = self._graph
+        if g is None or g["key"] != key:
+            self._graph = g = {"key": key, "warm": 0}     # new shapes / loss blend: drop the old graph, warm up again
+        if "graph" not in g:
+            if g["warm"] < 2:    # eager warm-up: lazy initialisation (workspaces, autograd) must not be captured
+                g["warm"] += 1
+                return self._eager_step(img, mask, distmap, alpha)
+            self._capture(g, img, mask, distmap, alpha)
+        g["img"].copy_(img)
+        g["mask"].copy_(mask)
+        if distmap is not None:
+            g["distmap"].copy_(distmap)
+        self.opt.t += 1                      # host mirror of the device step counter g["t"]
+        if g["lr_value"] != self.opt.lr:     # stream-ordered fill (value travels as a kernel argument): no host
+            g["lr"].fill_(self.opt.lr)       # buffer the run-ahead host could overwrite before the GPU reads it
+            g["lr_value"] = self.opt.lr
+        g["graph"].replay()
+        self.model.engine.mark_weights_changed()
+        self.last = g["last"]
+        return g["last"]["loss"]
+
+    def _capture(self, g, img, mask, distmap, alpha):
+        m, eng = self.model, self.model.engine
+        dev = img.device
+        g["img"], g["mask"] = img.clone(), mask.clone()
+        g["distmap"] = None if distmap is None else distmap.clone()
+        # Adam's per-step scalars live on the device: step counter, learning rate, and (lr, 1-b1^t, 1-b2^t)
+        g["t"] = torch.tensor([float(self.opt.t)], dtype=torch.float64, device=dev)
+        g["lr"] = torch.tensor([float(self.opt.lr)], dtype=torch.float64, device=dev)
+        g["lr_value"] = self.opt.lr
+        g["hyper"] = torch.ones(3, dtype=torch.float32, device=dev)
+        eager_ws, eng._ws = eng._ws, {}       # workspaces of the captured step live (and stay) in the graph's pool
+        graph = torch.cuda.CUDAGraph()
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                b1, b2 = self.opt.betas
+                g["t"].add_(1.0)
+                g["hyper"].copy_(torch.cat([g["lr"], 1.0 - torch.pow(b1, g["t"]), 1.0 - torch.pow(b2, g["t"])]))
+                self._eager_step(g["img"], g["mask"], g["distmap"], alpha, hyper=g["hyper"])
+        finally:
+            g["ws"], eng._ws = eng._ws, eager_ws
+        g["graph"], g["last"] = graph, self.last
+
+    def _eager_step(self, img, mask, distmap, alpha, hyper=None):
         m = self.model
         m.train()
         m.flat_params.grad = None
@@ -87,7 +147,7 @@ class HipTrainer:
             self.reducer.wait()
         # non-finite loss -> skip the update (reference segmodel.py:220-222 returns None)
         skip = (~torch.isfinite(loss.detach())).to(torch.int32).reshape(1)
-        norm = self.opt.step(m._grad_buffer(), grad_scale=1.0 / self.world, skip_flag=skip)
+        norm = self.opt.step(m._grad_buffer(), grad_scale=1.0 / self.world, skip_flag=skip, hyper=hyper)
         m.engine.mark_weights_changed()   # the fused optimiser wrote the flat buffer behind torch's version counter
         m.flat_params.grad = None
         self.last = {"loss": loss.detach(), "parts": parts, "grad_norm": norm, "label_error": err, "skipped": skip}

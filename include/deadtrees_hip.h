@@ -282,6 +282,10 @@ int dt_clip_coef(const double* partial, int rows, float max_norm, float gscale, 
 int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, float bias_c1, float bias_c2, const float* clipcoef, const int32_t* skip_flag,
                  void* stream);
+/* the same step with the per-step scalars on the device: hyper fp32 [3] = (lr, 1 - beta1^t, 1 - beta2^t), so a
+ * training step captured in a HIP graph replays with the current learning rate and bias corrections. */
+int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                     float beta2, float eps, const float* clipcoef, const int32_t* skip_flag, void* stream);
 
 #ifdef __cplusplus
 }

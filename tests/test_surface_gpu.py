@@ -243,3 +243,37 @@ def test_device_train_transform_matches_numpy_restatement():
     assert abs(float((geo_d[:, 0] == 1).float().mean()) - 0.25) < 0.03
     assert abs(float((geo_d[:, 1] == 0).float().mean()) - 0.625) < 0.03      # p=0.5 none + 1/4 of the applied draws
     assert abs(float((bc_d[:, 0] != 1).float().mean()) - 0.5) < 0.03
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replayed_training_equals_eager(precision):
+    """HipTrainer(graph=True): two eager steps, capture, replays.  The captured step launches the same kernels in
+    the same order, so after N steps parameters, Adam state and losses equal the eager trainer's bit for bit
+    (Adam's step count / learning rate are read from the device inside the graph)."""
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.trainer import HipTrainer
+    from oracle.unet_ref import make_oracle
+    ref = make_oracle(3, 2, seed=0)
+    batches = [tuple(t.to(DEV) for t in synth_batch(2, 128, 128, 3, 2, seed=s)) for s in range(3)]
+    out = {}
+    for mode in ("eager", "graph"):
+        m = UNetHIP()
+        m.load_state_dict(ref.state_dict())
+        m.to(DEV)
+        tr = HipTrainer(m, precision=precision, graph=(mode == "graph"))
+        losses = []
+        for step in range(7):
+            if step == 5:
+                tr.opt.lr = 1e-4                      # a learning-rate change must reach the replayed step
+            img, mask = batches[step % 3]
+            losses.append(float(tr.step(img, mask)))
+        out[mode] = (losses, m.flat_params.detach().clone(), tr.opt.m.clone(), tr.opt.v.clone(), m.bn_state.clone(),
+                     tr.opt.t)
+        if mode == "graph":
+            assert tr._graph is not None and "graph" in tr._graph
+    le, pe, me, ve, be, te = out["eager"]
+    lg, pg, mg, vg, bg, tg = out["graph"]
+    assert te == tg == 7
+    assert le == lg, (le, lg)
+    assert torch.equal(pe, pg) and torch.equal(me, mg) and torch.equal(ve, vg) and torch.equal(be, bg)
