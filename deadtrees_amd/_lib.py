@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeadtrees_hip.so")
+# DT_HIP_LIB points at another build of the same ABI (kernel experiments); default: the in-tree library
+LIB_PATH = os.environ.get("DT_HIP_LIB") or os.path.join(_HERE, "libdeadtrees_hip.so")
 
 c_f = C.c_void_p  # device pointers travel as raw addresses
 I32, I64, F32, F64, SZ = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_size_t
