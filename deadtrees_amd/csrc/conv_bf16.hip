@@ -27,9 +27,11 @@ struct ConvBfArgs {
   int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, n_tiles, P, cout_split, accumulate;
 };
 
-#define BF_CK 32
-#define BF_PITCH 40   // bf16 elements per LDS row (32 used): 80 bytes
+#define BF_CK 32      // channels per chunk of the wide kernels; LDS rows hold CK channels at a pitch of CK + 8 bf16:
+                      // 80 B (CK 32) or 48 B (CK 16) — both keep every 8-lane ds_read_b128 / ds_write_b128 group on
+                      // distinct banks
 #define BF_TF_MAXC 512
+#define BF_NARROW_CIN 32   // up to this many input channels the 16-channel-chunk kernel is used (if Cout < 64)
 
 template <int KS, int STRIDE, int TW>
 struct BfGeom {
@@ -41,9 +43,13 @@ struct BfGeom {
   static constexpr int TAPS = KS * KS;
 };
 
-template <int KS, int STRIDE, int TW, int TN, bool TF>
+// CK = 16 (with TN = 32) is the variant for the full-resolution decoder end (Cin <= 32): 30 KB of LDS and ~100
+// VGPRs instead of 50 KB / 140, so five workgroups per CU instead of three keep loads in flight — those layers
+// are bound by memory latency per workgroup, not by MFMA or LDS.
+template <int KS, int STRIDE, int TW, int TN, int CK, bool TF>
 __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs a) {
   using G = BfGeom<KS, STRIDE, TW>;
+  constexpr int BF_PITCH = CK + 8, SEG = CK / 8, ROWS_IT = 256 / SEG;
   constexpr int NT = TN / 32;
   constexpr int IN_ROWS = G::HALO_H * G::HALO_W;
   constexpr int W_ROWS = G::TAPS * TN;
@@ -53,13 +59,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   constexpr int LDS_OUTF = 256 * OUTF_PITCH * 2;   // in bf16 elements
   static_assert(LDS_OUTF >= LDS_OUT, "fp32 staging is the larger image");
   __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_MAIN > LDS_OUTF ? LDS_MAIN : LDS_OUTF];
-  __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 2 * BF_TF_MAXC : 4];
+  constexpr int TFC = CK == 16 ? BF_NARROW_CIN : BF_TF_MAXC;   // channels of the input-transform table
+  __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 2 * TFC : 4];
   __bf16* lds_in = lds;
   __bf16* lds_w = lds + IN_ROWS * BF_PITCH;
   if constexpr (TF) {
     for (int i = threadIdx.x; i < a.C0; i += 256) {
       lds_tf[i] = a.in_scale[i];
-      lds_tf[BF_TF_MAXC + i] = a.in_shift[i];
+      lds_tf[TFC + i] = a.in_shift[i];
     }
   }
   const int wg = (int)xcd_remap(blockIdx.x, gridDim.x);
@@ -86,16 +93,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
 
-  // staging bookkeeping: 4 x 16-byte segments (8 channels) per row
-  constexpr int IN_TOTAL = IN_ROWS * 4, IN_IT = (IN_TOTAL + 255) / 256;
-  constexpr int W_TOTAL = W_ROWS * 4, W_IT = (W_TOTAL + 255) / 256;
-  const int q = tid & 3, row0 = tid >> 2;
+  // staging bookkeeping: SEG x 16-byte segments (8 channels) per row
+  constexpr int IN_TOTAL = IN_ROWS * SEG, IN_IT = (IN_TOTAL + 255) / 256;
+  constexpr int W_TOTAL = W_ROWS * SEG, W_IT = (W_TOTAL + 255) / 256;
+  const int q = tid % SEG, row0 = tid / SEG;
   const int Cin = a.C0 + a.C1;
   const int Hs0 = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.mode0 ? (a.Win >> 1) : a.Win;
   int pidx0[IN_IT], pidx1[IN_IT];
 #pragma unroll
   for (int it = 0; it < IN_IT; ++it) {
-    const int pix = row0 + it * 64;
+    const int pix = row0 + it * ROWS_IT;
     const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
     const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
     const bool inb = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && pix < IN_ROWS;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   int woff[W_IT];
 #pragma unroll
   for (int it = 0; it < W_IT; ++it) {
-    const int row = row0 + it * 64;  // tap*TN + n
+    const int row = row0 + it * ROWS_IT;  // tap*TN + n
     const int tap = row / TN, n = row - tap * TN;
     woff[it] = (row < W_ROWS && n0 + n < a.Cout) ? (tap * a.Cout + n0 + n) * Cin + 8 * q : -1;
   }
@@ -142,13 +149,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           sc[k] = lds_tf[cc + k];
-          sh[k] = lds_tf[BF_TF_MAXC + cc + k];
+          sh[k] = lds_tf[TFC + cc + k];
         }
       }
     }
 #pragma unroll
     for (int it = 0; it < IN_IT; ++it) {
-      const int pix = row0 + it * 64;
+      const int pix = row0 + it * ROWS_IT;
       if (IN_TOTAL % 256 == 0 || pix < IN_ROWS) {
         f32x4 raw = rin[it];
         if (TF && tf_on && pidx0[it] >= 0) {
@@ -166,22 +173,22 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
     }
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
-      const int row = row0 + it * 64;
+      const int row = row0 + it * ROWS_IT;
       if (W_TOTAL % 256 == 0 || row < W_ROWS) *reinterpret_cast<f32x4*>(lds_w + row * BF_PITCH + 8 * q) = rw[it];
     }
   };
 
   issue_loads(0);
-  for (int c0 = 0; c0 < Cin; c0 += BF_CK) {
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
     __syncthreads();
     write_lds(c0);
     __syncthreads();
-    if (c0 + BF_CK < Cin) issue_loads(c0 + BF_CK);
+    if (c0 + CK < Cin) issue_loads(c0 + CK);
 #pragma unroll
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int kh = tap / KS, kw = tap % KS;
 #pragma unroll
-      for (int ks = 0; ks < BF_CK / 16; ++ks) {
+      for (int ks = 0; ks < CK / 16; ++ks) {
         if (c0 + 16 * ks >= Cin) continue;   // Cin = 16 (mod 32): the second k-step of the last chunk is all zero
         bf16x8 av[2], bv[NT];
 #pragma unroll
@@ -323,30 +330,37 @@ static int bf_validate(const dt_conv_desc* d) {
   return DT_OK;
 }
 
-template <int KS, int STRIDE, int TW, int TN>
+template <int KS, int STRIDE, int TW, int TN, int CK>
 static int bf_launch(const ConvBfArgs& a, hipStream_t st) {
   const long grid = (long)a.P * a.n_tiles;
   if (a.in_scale != nullptr)
-    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, CK, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, CK, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
 
 template <int KS, int STRIDE>
-static int bf_dispatch(const ConvBfArgs& a, int tw, int tn, hipStream_t st) {
+static int bf_dispatch(const ConvBfArgs& a, int tw, int tn, int ck, hipStream_t st) {
   if (tn == 64) {
-    if (tw == 32) return bf_launch<KS, STRIDE, 32, 64>(a, st);
-    if (tw == 16) return bf_launch<KS, STRIDE, 16, 64>(a, st);
-    return bf_launch<KS, STRIDE, 8, 64>(a, st);
+    if (tw == 32) return bf_launch<KS, STRIDE, 32, 64, 32>(a, st);
+    if (tw == 16) return bf_launch<KS, STRIDE, 16, 64, 32>(a, st);
+    return bf_launch<KS, STRIDE, 8, 64, 32>(a, st);
   }
-  if (tw == 32) return bf_launch<KS, STRIDE, 32, 32>(a, st);
-  if (tw == 16) return bf_launch<KS, STRIDE, 16, 32>(a, st);
-  return bf_launch<KS, STRIDE, 8, 32>(a, st);
+  if constexpr (KS == 3 && STRIDE == 1) {
+    if (ck == 16) {
+      if (tw == 32) return bf_launch<KS, STRIDE, 32, 32, 16>(a, st);
+      if (tw == 16) return bf_launch<KS, STRIDE, 16, 32, 16>(a, st);
+      return bf_launch<KS, STRIDE, 8, 32, 16>(a, st);
+    }
+  }
+  if (tw == 32) return bf_launch<KS, STRIDE, 32, 32, 32>(a, st);
+  if (tw == 16) return bf_launch<KS, STRIDE, 16, 32, 32>(a, st);
+  return bf_launch<KS, STRIDE, 8, 32, 32>(a, st);
 }
 
-static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_) {
+static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_, int* ck_) {
   const int tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
   int tn = d->Cout >= 64 ? 64 : 32;
   if (d->cout_split > 0 && (d->cout_split % 64) != 0) tn = 32;
@@ -356,18 +370,19 @@ static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_) {
   }
   *tw_ = tw;
   *tn_ = tn;
+  *ck_ = (tn == 32 && d->ksize == 3 && d->stride == 1 && d->C1 == 0 && d->C0 <= BF_NARROW_CIN) ? 16 : 32;
 }
 
-extern "C" int dt_conv2d_bf16_config(const dt_conv_desc* d, int* tw, int* tn) {
+extern "C" int dt_conv2d_bf16_config(const dt_conv_desc* d, int* tw, int* tn, int* ck) {
   if (bf_validate(d) != DT_OK) return DT_EINVAL;
-  bf_cfg(d, tw, tn);
+  bf_cfg(d, tw, tn, ck);
   return DT_OK;
 }
 
 extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
   if (bf_validate(d) != DT_OK) return DT_EINVAL;
-  int tw, tn;
-  bf_cfg(d, &tw, &tn);
+  int tw, tn, ck;
+  bf_cfg(d, &tw, &tn, &ck);
   return d->B * dt_cdiv(d->Ho, 256 / tw) * dt_cdiv(d->Wo, tw);
 }
 
@@ -381,8 +396,8 @@ extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const voi
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_bf16: in_scale/in_shift must come together");
   DT_REQUIRE(in_scale == nullptr || d->C0 <= BF_TF_MAXC, "conv_bf16: input transform needs C0 <= %d", BF_TF_MAXC);
   DT_REQUIRE(d->cout_split == 0 || out1, "conv_bf16: out1 missing");
-  int tw, tn;
-  bf_cfg(d, &tw, &tn);
+  int tw, tn, ck;
+  bf_cfg(d, &tw, &tn, &ck);
   ConvBfArgs a;
   a.out1 = (__bf16*)out1; a.stats = stats; a.cout_split = d->cout_split; a.accumulate = d->accumulate;
   a.src0 = (const __bf16*)src0; a.src1 = (const __bf16*)src1; a.w = (const __bf16*)w_bf16;
@@ -392,10 +407,10 @@ extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const voi
   a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 256 / tw); a.n_tiles = dt_cdiv(d->Cout, tn);
   a.P = d->B * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
-  if (d->ksize == 3 && d->stride == 1) return bf_dispatch<3, 1>(a, tw, tn, st);
-  if (d->ksize == 3 && d->stride == 2) return bf_dispatch<3, 2>(a, tw, tn, st);
-  if (d->ksize == 1 && d->stride == 1) return bf_dispatch<1, 1>(a, tw, tn, st);
-  return bf_dispatch<1, 2>(a, tw, tn, st);
+  if (d->ksize == 3 && d->stride == 1) return bf_dispatch<3, 1>(a, tw, tn, ck, st);
+  if (d->ksize == 3 && d->stride == 2) return bf_dispatch<3, 2>(a, tw, tn, ck, st);
+  if (d->ksize == 1 && d->stride == 1) return bf_dispatch<1, 1>(a, tw, tn, ck, st);
+  return bf_dispatch<1, 2>(a, tw, tn, ck, st);
 }
 
 // ------------------------------------------------------------------ weights: fp32 HWIO -> bf16 [tap][Cout][Cin]
