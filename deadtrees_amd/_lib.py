@@ -75,7 +75,7 @@ SIGNATURES = {
     "dt_signed_distmap_workspace": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "dt_signed_distmap": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_conv2d_bf16_stat_rows": (C.c_int, [_P]),
-    "dt_conv2d_bf16_config": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dt_conv2d_bf16_config": (C.c_int, [_P] + [C.POINTER(C.c_int)] * 4),
     "dt_conv2d_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_wgrad_bf16_workspace": (SZ, [_P]),
     "dt_conv2d_wgrad_bf16": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),

@@ -33,9 +33,9 @@ struct ConvBfArgs {
 #define BF_TF_MAXC 512
 #define BF_NARROW_CIN 32   // up to this many input channels the 16-channel-chunk kernel is used (if Cout < 64)
 
-template <int KS, int STRIDE, int TW>
+template <int KS, int STRIDE, int TW, int TPX>
 struct BfGeom {
-  static constexpr int TH = 256 / TW;
+  static constexpr int TH = TPX / TW;
   static constexpr int LS = (KS == 1) ? 1 : STRIDE;
   static constexpr int GS = (KS == 1) ? STRIDE : 1;
   static constexpr int HALO_H = (TH - 1) * LS + KS;
@@ -46,9 +46,13 @@ struct BfGeom {
 // CK = 16 (with TN = 32) is the variant for the full-resolution decoder end (Cin <= 32): 30 KB of LDS and ~100
 // VGPRs instead of 50 KB / 140, so five workgroups per CU instead of three keep loads in flight — those layers
 // are bound by memory latency per workgroup, not by MFMA or LDS.
-template <int KS, int STRIDE, int TW, int TN, int CK, bool TF>
+// MT = MFMA row tiles (32 pixels) per wave: 2 -> 256-pixel workgroup tiles; 4 (with CK = 16) -> 512-pixel tiles.
+// The bf16 kernels are bound by global->LDS staging: a 512 x 64 tile stages 248 FLOP per byte
+// instead of 161 and needs 0.75 instead of 1 LDS fragment per MFMA; 16-channel chunks keep two workgroups per CU.
+template <int KS, int STRIDE, int TW, int TN, int CK, int MT, bool TF>
 __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs a) {
-  using G = BfGeom<KS, STRIDE, TW>;
+  constexpr int TPX = 128 * MT;
+  using G = BfGeom<KS, STRIDE, TW, TPX>;
   constexpr int BF_PITCH = CK + 8, SEG = CK / 8, ROWS_IT = 256 / SEG;
   constexpr int NT = TN / 32;
   constexpr int IN_ROWS = G::HALO_H * G::HALO_W;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   constexpr int LDS_OUTF = 256 * OUTF_PITCH * 2;   // in bf16 elements
   static_assert(LDS_OUTF >= LDS_OUT, "fp32 staging is the larger image");
   __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_MAIN > LDS_OUTF ? LDS_MAIN : LDS_OUTF];
-  constexpr int TFC = CK == 16 ? BF_NARROW_CIN : BF_TF_MAXC;   // channels of the input-transform table
+  constexpr int TFC = (CK == 16 && MT == 2) ? BF_NARROW_CIN : BF_TF_MAXC;   // channels of the input-transform table
   __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 2 * TFC : 4];
   __bf16* lds_in = lds;
   __bf16* lds_w = lds + IN_ROWS * BF_PITCH;
@@ -77,17 +81,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, r = lane & 31;
 
-  int abase[2];
+  // MFMA row tile (wave, mt) covers pixels [(mt/2)*256 + (wave*2 + mt%2)*32, +32): slices of 256 pixels for the epilogue
+  int abase[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int p = (wave * 2 + mt) * 32 + r;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int p = (mt >> 1) * 256 + (wave * 2 + (mt & 1)) * 32 + r;
     abase[mt] = ((p / TW) * G::LS * G::HALO_W + (p % TW) * G::LS) * BF_PITCH + h * 8;
   }
   const int bbase = r * BF_PITCH + h * 8;
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -190,15 +195,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
 #pragma unroll
       for (int ks = 0; ks < CK / 16; ++ks) {
         if (c0 + 16 * ks >= Cin) continue;   // Cin = 16 (mod 32): the second k-step of the last chunk is all zero
-        bf16x8 av[2], bv[NT];
+        bf16x8 av[MT], bv[NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           av[mt] = *reinterpret_cast<const bf16x8*>(lds_in + abase[mt] + (kh * G::HALO_W + kw) * BF_PITCH + ks * 16);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           bv[j] = *reinterpret_cast<const bf16x8*>(lds_w + bbase + (tap * TN + 32 * j) * BF_PITCH + ks * 16);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[j], acc[mt][j], 0, 0, 0);
@@ -220,73 +225,78 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   const bool join = a.accumulate && !second;
   constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS;
   const int seg = tid % SEGS, prow = tid / SEGS;
-  __syncthreads();   // every wave is done with the operand images
-  if (!join) {
+  // the tile is written out in slices of 256 pixels (MT / 2 of them) through the same staging image
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+  for (int sl = 0; sl < MT / 2; ++sl) {
+    __syncthreads();   // every wave is done with the operand images / the previous slice
+    const int pbase = sl * 256;
+    if (!join) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int p = (wave * 2 + mt) * 32 + mrow;
-          const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-          const float v = acc[mt][j][i];
-          if (n0 + 32 * j + r < a.Cout && oy < a.Ho && ox < a.Wo) {
-            s1[j] += v;
-            s2[j] += v * v;
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int pl = (wave * 2 + m2) * 32 + mrow;
+            const int oy = oy0 + (pbase + pl) / TW, ox = ox0 + (pbase + pl) % TW;
+            const float v = acc[2 * sl + m2][j][i];
+            if (n0 + 32 * j + r < a.Cout && oy < a.Ho && ox < a.Wo) {
+              s1[j] += v;
+              s2[j] += v * v;
+            }
+            lds[pl * OUT_PITCH + 32 * j + r] = (__bf16)v;
           }
-          lds[p * OUT_PITCH + 32 * j + r] = (__bf16)v;
+      __syncthreads();
+      if (n0 + 8 * seg < a.Cout) {
+#pragma unroll
+        for (int it = 0; it < SEGS; ++it) {
+          const int pl = prow + it * PER_IT;
+          const int oy = oy0 + (pbase + pl) / TW, ox = ox0 + (pbase + pl) % TW;
+          if (oy < a.Ho && ox < a.Wo)
+            *reinterpret_cast<f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) =
+                *reinterpret_cast<const f32x4*>(lds + pl * OUT_PITCH + 8 * seg);
         }
-    __syncthreads();
-    if (n0 + 8 * seg < a.Cout) {
-#pragma unroll
-      for (int it = 0; it < SEGS; ++it) {
-        const int p = prow + it * PER_IT;
-        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        if (oy < a.Ho && ox < a.Wo)
-          *reinterpret_cast<f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) =
-              *reinterpret_cast<const f32x4*>(lds + p * OUT_PITCH + 8 * seg);
       }
-    }
-  } else {
-    float* ldsf = reinterpret_cast<float*>(lds);
+    } else {
+      float* ldsf = reinterpret_cast<float*>(lds);
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+        for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int p = (wave * 2 + mt) * 32 + mrow;
-          ldsf[p * OUTF_PITCH + 32 * j + r] = acc[mt][j][i];
-        }
-    __syncthreads();
-    if (n0 + 8 * seg < a.Cout) {
-      f32x4 prev[SEGS];
-#pragma unroll
-      for (int it = 0; it < SEGS; ++it) {
-        const int p = prow + it * PER_IT;
-        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (oy < a.Ho && ox < a.Wo)
-          v = *reinterpret_cast<const f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg);
-        prev[it] = v;
-      }
-#pragma unroll
-      for (int it = 0; it < SEGS; ++it) {
-        const int p = prow + it * PER_IT;
-        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        if (oy < a.Ho && ox < a.Wo) {
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(ldsf + p * OUTF_PITCH + 8 * seg);
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(ldsf + p * OUTF_PITCH + 8 * seg + 4);
-          bf16x8 o = *reinterpret_cast<bf16x8*>(&prev[it]);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            o[k] = (__bf16)(lo[k] + (float)o[k]);
-            o[4 + k] = (__bf16)(hi[k] + (float)o[4 + k]);
+          for (int i = 0; i < 16; ++i) {
+            const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int pl = (wave * 2 + m2) * 32 + mrow;
+            ldsf[pl * OUTF_PITCH + 32 * j + r] = acc[2 * sl + m2][j][i];
           }
-          *reinterpret_cast<bf16x8*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) = o;
+      __syncthreads();
+      if (n0 + 8 * seg < a.Cout) {
+        f32x4 prev[SEGS];
+#pragma unroll
+        for (int it = 0; it < SEGS; ++it) {
+          const int pl = prow + it * PER_IT;
+          const int oy = oy0 + (pbase + pl) / TW, ox = ox0 + (pbase + pl) % TW;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (oy < a.Ho && ox < a.Wo)
+            v = *reinterpret_cast<const f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg);
+          prev[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < SEGS; ++it) {
+          const int pl = prow + it * PER_IT;
+          const int oy = oy0 + (pbase + pl) / TW, ox = ox0 + (pbase + pl) % TW;
+          if (oy < a.Ho && ox < a.Wo) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ldsf + pl * OUTF_PITCH + 8 * seg);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ldsf + pl * OUTF_PITCH + 8 * seg + 4);
+            bf16x8 o = *reinterpret_cast<bf16x8*>(&prev[it]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              o[k] = (__bf16)(lo[k] + (float)o[k]);
+              o[4 + k] = (__bf16)(hi[k] + (float)o[4 + k]);
+            }
+            *reinterpret_cast<bf16x8*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) = o;
+          }
         }
       }
     }
@@ -330,37 +340,38 @@ static int bf_validate(const dt_conv_desc* d) {
   return DT_OK;
 }
 
-template <int KS, int STRIDE, int TW, int TN, int CK>
+template <int KS, int STRIDE, int TW, int TN, int CK, int MT>
 static int bf_launch(const ConvBfArgs& a, hipStream_t st) {
   const long grid = (long)a.P * a.n_tiles;
   if (a.in_scale != nullptr)
-    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, CK, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, CK, MT, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, CK, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_bf16_kernel<KS, STRIDE, TW, TN, CK, MT, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
 
 template <int KS, int STRIDE>
-static int bf_dispatch(const ConvBfArgs& a, int tw, int tn, int ck, hipStream_t st) {
-  if (tn == 64) {
-    if (tw == 32) return bf_launch<KS, STRIDE, 32, 64, 32>(a, st);
-    if (tw == 16) return bf_launch<KS, STRIDE, 16, 64, 32>(a, st);
-    return bf_launch<KS, STRIDE, 8, 64, 32>(a, st);
-  }
+static int bf_dispatch(const ConvBfArgs& a, int tw, int tn, int ck, int mt, hipStream_t st) {
   if constexpr (KS == 3 && STRIDE == 1) {
+    if (mt == 4) return bf_launch<KS, STRIDE, 32, 64, 16, 4>(a, st);   // 512-pixel tiles: TW 32, TN 64, CK 16 only
     if (ck == 16) {
-      if (tw == 32) return bf_launch<KS, STRIDE, 32, 32, 16>(a, st);
-      if (tw == 16) return bf_launch<KS, STRIDE, 16, 32, 16>(a, st);
-      return bf_launch<KS, STRIDE, 8, 32, 16>(a, st);
+      if (tw == 32) return bf_launch<KS, STRIDE, 32, 32, 16, 2>(a, st);
+      if (tw == 16) return bf_launch<KS, STRIDE, 16, 32, 16, 2>(a, st);
+      return bf_launch<KS, STRIDE, 8, 32, 16, 2>(a, st);
     }
   }
-  if (tw == 32) return bf_launch<KS, STRIDE, 32, 32, 32>(a, st);
-  if (tw == 16) return bf_launch<KS, STRIDE, 16, 32, 32>(a, st);
-  return bf_launch<KS, STRIDE, 8, 32, 32>(a, st);
+  if (tn == 64) {
+    if (tw == 32) return bf_launch<KS, STRIDE, 32, 64, 32, 2>(a, st);
+    if (tw == 16) return bf_launch<KS, STRIDE, 16, 64, 32, 2>(a, st);
+    return bf_launch<KS, STRIDE, 8, 64, 32, 2>(a, st);
+  }
+  if (tw == 32) return bf_launch<KS, STRIDE, 32, 32, 32, 2>(a, st);
+  if (tw == 16) return bf_launch<KS, STRIDE, 16, 32, 32, 2>(a, st);
+  return bf_launch<KS, STRIDE, 8, 32, 32, 2>(a, st);
 }
 
-static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_, int* ck_) {
+static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_, int* ck_, int* mt_) {
   const int tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
   int tn = d->Cout >= 64 ? 64 : 32;
   if (d->cout_split > 0 && (d->cout_split % 64) != 0) tn = 32;
@@ -371,19 +382,30 @@ static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_, int* ck_) {
   *tw_ = tw;
   *tn_ = tn;
   *ck_ = (tn == 32 && d->ksize == 3 && d->stride == 1 && d->C1 == 0 && d->C0 <= BF_NARROW_CIN) ? 16 : 32;
+  *mt_ = 2;
+  if (tn == 64 && tw == 32 && d->ksize == 3 && d->stride == 1 && (d->C0 % 16) == 0 && (d->C1 % 16) == 0 && d->Ho >= 16 &&
+      d->Cout >= 128) {
+    // 512-pixel tiles when they still fill the chip twice over.  Measured per layer (scripts/bench_conv.py, B=64):
+    // +8 % on 128->128 @64x64, +5 % on 384->128 @64x64, nothing on 64-channel outputs (one n-tile) -> Cout >= 128 only
+    const long wgs = (long)d->B * dt_cdiv(d->Ho, 16) * dt_cdiv(d->Wo, 32) * dt_cdiv(d->Cout, 64);
+    if (wgs >= 1024) {
+      *mt_ = 4;
+      *ck_ = 16;
+    }
+  }
 }
 
-extern "C" int dt_conv2d_bf16_config(const dt_conv_desc* d, int* tw, int* tn, int* ck) {
+extern "C" int dt_conv2d_bf16_config(const dt_conv_desc* d, int* tw, int* tn, int* ck, int* mt) {
   if (bf_validate(d) != DT_OK) return DT_EINVAL;
-  bf_cfg(d, tw, tn, ck);
+  bf_cfg(d, tw, tn, ck, mt);
   return DT_OK;
 }
 
 extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
   if (bf_validate(d) != DT_OK) return DT_EINVAL;
-  int tw, tn, ck;
-  bf_cfg(d, &tw, &tn, &ck);
-  return d->B * dt_cdiv(d->Ho, 256 / tw) * dt_cdiv(d->Wo, tw);
+  int tw, tn, ck, mt;
+  bf_cfg(d, &tw, &tn, &ck, &mt);
+  return d->B * dt_cdiv(d->Ho, 128 * mt / tw) * dt_cdiv(d->Wo, tw);
 }
 
 extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16,
@@ -396,21 +418,21 @@ extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const voi
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_bf16: in_scale/in_shift must come together");
   DT_REQUIRE(in_scale == nullptr || d->C0 <= BF_TF_MAXC, "conv_bf16: input transform needs C0 <= %d", BF_TF_MAXC);
   DT_REQUIRE(d->cout_split == 0 || out1, "conv_bf16: out1 missing");
-  int tw, tn, ck;
-  bf_cfg(d, &tw, &tn, &ck);
+  int tw, tn, ck, mt;
+  bf_cfg(d, &tw, &tn, &ck, &mt);
   ConvBfArgs a;
   a.out1 = (__bf16*)out1; a.stats = stats; a.cout_split = d->cout_split; a.accumulate = d->accumulate;
   a.src0 = (const __bf16*)src0; a.src1 = (const __bf16*)src1; a.w = (const __bf16*)w_bf16;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out = (__bf16*)out;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.pad = d->pad;
-  a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 256 / tw); a.n_tiles = dt_cdiv(d->Cout, tn);
+  a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 128 * mt / tw); a.n_tiles = dt_cdiv(d->Cout, tn);
   a.P = d->B * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
-  if (d->ksize == 3 && d->stride == 1) return bf_dispatch<3, 1>(a, tw, tn, ck, st);
-  if (d->ksize == 3 && d->stride == 2) return bf_dispatch<3, 2>(a, tw, tn, ck, st);
-  if (d->ksize == 1 && d->stride == 1) return bf_dispatch<1, 1>(a, tw, tn, ck, st);
-  return bf_dispatch<1, 2>(a, tw, tn, ck, st);
+  if (d->ksize == 3 && d->stride == 1) return bf_dispatch<3, 1>(a, tw, tn, ck, mt, st);
+  if (d->ksize == 3 && d->stride == 2) return bf_dispatch<3, 2>(a, tw, tn, ck, mt, st);
+  if (d->ksize == 1 && d->stride == 1) return bf_dispatch<1, 1>(a, tw, tn, ck, mt, st);
+  return bf_dispatch<1, 2>(a, tw, tn, ck, mt, st);
 }
 
 // ------------------------------------------------------------------ weights: fp32 HWIO -> bf16 [tap][Cout][Cin]

@@ -279,8 +279,8 @@ class UNetEngine:
         if prof is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            tw, tn, ck = C.c_int(), C.c_int(), C.c_int()
-            self.lib.dt_conv2d_bf16_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck))
+            tw, tn, ck, mt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            self.lib.dt_conv2d_bf16_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck), C.byref(mt))
             flops = 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout * desc.Ho * desc.Wo * desc.B
             if desc.mode0 == 2:
                 flops /= 4.0
@@ -288,7 +288,7 @@ class UNetEngine:
             nbytes = 2.0 * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
                                      desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
                 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
-            name = (f"conv_fwd_bf16_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, "
+            name = (f"conv_fwd_bf16_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, {mt.value}, "
                     f"{'true' if in_ss else 'false'}>")
             prof.append((name, flops, e0, e1, nbytes))
 

@@ -224,7 +224,7 @@ int dt_signed_distmap(const int64_t* labels, float* dist, void* workspace, int32
  * dt_conv2d (mode0 0/1/2, concat, split outputs, accumulate, BatchNorm partial statistics from the fp32
  * accumulators, fused input BatchNorm-apply + ReLU). */
 int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d);
-int dt_conv2d_bf16_config(const dt_conv_desc* d, int* tile_w, int* tile_n, int* chunk_k);  /* conv_fwd_bf16_kernel<k,s,tw,tn,tf> */
+int dt_conv2d_bf16_config(const dt_conv_desc* d, int* tile_w, int* tile_n, int* chunk_k, int* row_tiles);  /* conv_fwd_bf16_kernel<k,s,tw,tn,tf> */
 int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16, void* out,
                    void* out1, float* stats, const float* in_scale, const float* in_shift, void* stream);
 int dt_pack_weights_bf16(const float* w_hwio, void* out_bf16, int ksize, int Cin, int Cout, void* stream);

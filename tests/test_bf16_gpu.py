@@ -32,7 +32,9 @@ def close_bf16(got, ref, extra=0.0):
 
 CASES = [(2, 32, 32, 64, 64, 3, 1, 1), (1, 40, 24, 16, 16, 3, 1, 1), (2, 16, 16, 128, 96, 3, 1, 1),
          (2, 8, 8, 32, 48, 3, 1, 1), (2, 32, 32, 64, 128, 3, 2, 1), (2, 32, 32, 64, 128, 1, 2, 0),
-         (1, 34, 70, 512, 64, 3, 1, 1)]
+         (1, 34, 70, 512, 64, 3, 1, 1),
+         # 512-pixel workgroup tiles (Cout >= 128 and >= 1024 tiles): ragged bottom edge, 2 n-tiles, Cin = 16 (mod 32)
+         (16, 120, 128, 48, 128, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
@@ -53,10 +55,11 @@ def test_conv_bf16_forward_and_stats(B, H, W, Cin, Cout, k, s, p):
     np.testing.assert_allclose(stats[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4)
 
 
-def test_conv_bf16_upsample_concat_transform_split_accumulate():
+@pytest.mark.parametrize("B,h,w_,Cout", [(2, 10, 12, 96), (16, 64, 64, 192)])   # the second: 512-pixel tiles
+def test_conv_bf16_upsample_concat_transform_split_accumulate(B, h, w_, Cout):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
-    B, h, w_, C0, C1, Cout = 2, 10, 12, 64, 32, 96
+    C0, C1 = 64, 32
     a = torch.randn((B, C0, h, w_), generator=g)
     skip = torch.randn((B, C1, 2 * h, 2 * w_), generator=g)
     sc = 1 + 0.3 * torch.randn(C0, generator=g)
