@@ -155,15 +155,30 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const f32x4* __restrict__ y
                                                      const float* __restrict__ rscale,
                                                      const float* __restrict__ rshift, f32x4* __restrict__ out,
                                                      int64_t n4, int C4, int relu) {
+  // When the grid stride is a multiple of C4 a thread stays on one channel quad: its coefficients are loaded once
+  // (they are L1 hits, but every per-iteration 16-byte coefficient load costs the same issue slot as a data load).
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int c4 = (int)(i % C4);
-    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4];
-    const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool fixed = (stride % C4) == 0;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  int c4 = (int)(i0 % C4);
+  f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4], sh = reinterpret_cast<const f32x4*>(shift)[c4];
+  f32x4 rsc = rscale ? reinterpret_cast<const f32x4*>(rscale)[c4] : one;
+  f32x4 rsh = rscale ? reinterpret_cast<const f32x4*>(rshift)[c4] : zero;
+  for (int64_t i = i0; i < n4; i += stride) {
+    if (!fixed) {
+      c4 = (int)(i % C4);
+      sc = reinterpret_cast<const f32x4*>(scale)[c4];
+      sh = reinterpret_cast<const f32x4*>(shift)[c4];
+      if (rscale) {
+        rsc = reinterpret_cast<const f32x4*>(rscale)[c4];
+        rsh = reinterpret_cast<const f32x4*>(rshift)[c4];
+      }
+    }
     f32x4 v = y[i] * sc + sh;
     if (res) {
       f32x4 rv = res[i];
-      if (rscale) rv = rv * reinterpret_cast<const f32x4*>(rscale)[c4] + reinterpret_cast<const f32x4*>(rshift)[c4];
+      if (rscale) rv = rv * rsc + rsh;
       v += rv;
     }
     if (relu) {
@@ -196,10 +211,17 @@ extern "C" int dt_bn_act(const float* y, const float* scale, const float* shift,
 // pass 1: per-channel partial sums of g and g*xhat over blocks of BNB_RB pixels.
 // 256 threads = Q channel-quads x (256/Q) pixel lanes; 2 pixels in flight per thread.
 #define BNB_RB 256
+// rows (pixels) per workgroup: 256 for small maps, grown so that a launch has at most ~2048 row blocks
+static inline int64_t bnb_rb(int64_t n_pix) {
+  int64_t rb = BNB_RB;
+  const int64_t want = (n_pix + 2047) / 2048;
+  if (want > rb) rb = (want + BNB_RB - 1) / BNB_RB * BNB_RB;
+  return rb;
+}
 
 extern "C" int dt_bn_bwd_rows(int64_t n_pix, int C) {
   (void)C;
-  return dt_cdiv(n_pix, BNB_RB);
+  return dt_cdiv(n_pix, bnb_rb(n_pix));
 }
 extern "C" int64_t dt_bn_bwd_red_floats(int64_t n_pix, int C) { return dt_bn_stats_floats(dt_bn_bwd_rows(n_pix, C), C); }
 
@@ -211,13 +233,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restr
                                                             const float* __restrict__ act_scale,
                                                             const float* __restrict__ act_shift,
                                                             float* __restrict__ red, int64_t n_pix, int C4, int Q,
-                                                            int P) {
+                                                            int P, int64_t RB) {
   __shared__ f32x4 sh[2][256];
   const int t = threadIdx.x;
   const int q = t % Q, rl = t / Q, RL = 256 / Q;
   const int cq = blockIdx.x * Q + q;
-  const int64_t p0 = (int64_t)blockIdx.y * BNB_RB;
-  int64_t p1 = p0 + BNB_RB;
+  const int64_t p0 = (int64_t)blockIdx.y * RB;
+  int64_t p1 = p0 + RB;
   if (p1 > n_pix) p1 = n_pix;
   const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[cq];
   const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[cq];
@@ -269,14 +291,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const f32x4* __restr
   sh[0][t] = sg0 + sg1;
   sh[1][t] = sx0 + sx1;
   __syncthreads();
-  if (rl == 0) {
-    f32x4 a = sh[0][q], b = sh[1][q];
-    for (int i = 1; i < RL; ++i) {
-      a += sh[0][i * Q + q];
-      b += sh[1][i * Q + q];
+  // pairwise tree over the row lanes (thread t = rl * Q + q): fixed order -> deterministic
+  for (int s = RL >> 1; s >= 1; s >>= 1) {
+    if (rl < s) {
+      sh[0][t] += sh[0][t + s * Q];
+      sh[1][t] += sh[1][t + s * Q];
     }
-    reinterpret_cast<f32x4*>(red)[(size_t)blockIdx.y * C4 + cq] = a;
-    reinterpret_cast<f32x4*>(red)[((size_t)P + blockIdx.y) * C4 + cq] = b;
+    __syncthreads();
+  }
+  if (rl == 0) {
+    reinterpret_cast<f32x4*>(red)[(size_t)blockIdx.y * C4 + cq] = sh[0][t];
+    reinterpret_cast<f32x4*>(red)[((size_t)P + blockIdx.y) * C4 + cq] = sh[1][t];
   }
 }
 
@@ -290,7 +315,8 @@ extern "C" int dt_bn_bwd_reduce(const float* dout, const float* out_act, const f
   DT_REQUIRE(C4 % Q == 0, "bn_bwd_reduce: C/4 must be a power of two or a multiple of 64 (C=%d)", C);
   const int P = dt_bn_bwd_rows(n_pix, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C4 / Q, P), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dout,
-                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, act_scale, act_shift, red, n_pix, C4, Q, P);
+                     (const f32x4*)out_act, (const f32x4*)y, mean, invstd, act_scale, act_shift, red, n_pix, C4, Q, P,
+                     bnb_rb(n_pix));
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -342,9 +368,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dgamma, const float* __restrict__ dbeta, const float* __restrict__ act_scale,
     const float* __restrict__ act_shift, f32x4* __restrict__ dy, f32x4* __restrict__ dres, int dres_acc, int64_t n4,
     int C4, float inv_count) {
+  // one channel quad per thread when the grid stride is a multiple of C4 (see bn_act_kernel): 5-7 coefficient loads
+  // per element group become 5-7 per thread
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const int c4 = (int)(i % C4);
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool fixed = (stride % C4) == 0;
+  f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f}, mu, is, gi, kb, kg;
+  auto load_coef = [&](int c4) {
+    if (act_scale) {
+      asc = reinterpret_cast<const f32x4*>(act_scale)[c4];
+      ash = reinterpret_cast<const f32x4*>(act_shift)[c4];
+    }
+    mu = reinterpret_cast<const f32x4*>(mean)[c4];
+    is = reinterpret_cast<const f32x4*>(invstd)[c4];
+    gi = reinterpret_cast<const f32x4*>(gamma)[c4] * is;
+    kb = reinterpret_cast<const f32x4*>(dbeta)[c4] * inv_count;
+    kg = reinterpret_cast<const f32x4*>(dgamma)[c4] * inv_count;
+  };
+  load_coef((int)(i0 % C4));
+  for (int64_t i = i0; i < n4; i += stride) {
+    if (!fixed) load_coef((int)(i % C4));
     f32x4 g = dout[i];
     const f32x4 yv = y[i];
     if (out_act) {
@@ -352,7 +395,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
       for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
     } else if (act_scale) {
-      const f32x4 a = yv * reinterpret_cast<const f32x4*>(act_scale)[c4] + reinterpret_cast<const f32x4*>(act_shift)[c4];
+      const f32x4 a = yv * asc + ash;
 #pragma unroll
       for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
     }
@@ -362,13 +405,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       else
         dres[i] = g;
     }
-    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4];
-    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c4];
-    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
-    const f32x4 dg = reinterpret_cast<const f32x4*>(dgamma)[c4];
-    const f32x4 db = reinterpret_cast<const f32x4*>(dbeta)[c4];
     const f32x4 xh = (yv - mu) * is;
-    dy[i] = ga * is * (g - db * inv_count - xh * (dg * inv_count));
+    dy[i] = gi * (g - kb - xh * kg);
   }
 }
 
