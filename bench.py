@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole training step as one HIP graph (auto: single-GPU bf16, where the step "
-                         "is shorter than the Python launch path; never with --gpus > 1)")
+                         "is shorter than the Python launch path; multi-GPU runs only with --graph on)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE configs[1] (headline); bf16 = configs[2] (bf16 storage, fp32 accumulate)")
@@ -85,7 +85,9 @@ def main():
     model.to(dev)
     if args.mode == "infer":
         return infer_bench(args, model, dev, world, rank, distributed)
-    use_graph = (not distributed) and (args.graph == "on" or (args.graph == "auto" and args.precision == "bf16"))
+    # auto: graph replay only where the step is launch-bound (single-GPU bf16); fp32 and every multi-GPU run stay
+    # eager by default so that the 1/2/4/8-GPU numbers come from one code path ("on" forces it, RCCL included)
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.precision == "bf16" and not distributed)
     tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed,
                     precision=args.precision, graph=use_graph)
     tr.broadcast_parameters(0)

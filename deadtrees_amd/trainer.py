@@ -52,7 +52,7 @@ class HipTrainer:
                  precision: str = "fp32", graph: bool = False):
         """graph=True: after two eager steps the whole step (forward, loss, backward, clip, Adam) is captured into a
         HIP graph and replayed — ~750 kernel launches become one, which matters once the bf16 step is shorter than
-        the Python launch path.  Single-GPU only (the gradient all-reduce hook stays eager)."""
+        the Python launch path."""
         if not model.flat_params.is_cuda:
             raise RuntimeError("HipTrainer needs the model on an MI355X (model.to('cuda'))")
         self.model = model
@@ -68,8 +68,8 @@ class HipTrainer:
             self.reducer.attach(model._grad_buffer())
             model.engine.grad_hook = self.reducer.hook
         self.last = {}
-        if graph and distributed:
-            raise ValueError("graph=True is a single-GPU mode; the bucketed all-reduce path launches eagerly")
+        # with distributed=True the bucketed RCCL all-reduces are captured too (rehearsed at world size 1 on RCCL 2.26;
+        # bench.py keeps multi-GPU runs eager until that has run on a real 8-GPU node)
         self.use_graph = bool(graph)
         self._graph = None
 
