@@ -65,31 +65,43 @@ def test_forward_eval_parity_and_argmax(B, H, W, C, K):
     assert float(safe.float().mean()) > 0.99
 
 
-def test_train_step_gradient_parity():
-    """loss + every parameter gradient of one training step vs the oracle.
+@pytest.mark.parametrize("C,K,names", [(3, 2, ("GDICE", "FOCAL")), (4, 3, ("DICE", "FOCAL", "BOUNDARY")),
+                                       (3, 3, ("GWDICE", "FOCAL"))])
+def test_train_step_gradient_parity(C, K, names):
+    """loss + every parameter gradient of one training step vs the oracle (RGB / RGBN, 2 / 3 classes, each dice
+    flavour, boundary loss on device-built distance maps).
 
     End-to-end gradients of a ReLU/max-pool network are ill-conditioned in fp32 (an activation within
     rounding distance of zero flips its mask), so the yardstick is the fp64 oracle: the HIP result must
-    be as close to it as the fp32 CPU oracle is (factor 3), tensor by tensor.  Exact per-kernel backward
+    be as close to it as the fp32 CPU oracle is (factor 4 per tensor, factor 2 over all parameters).  Exact per-kernel backward
     parity is covered in tests/test_kernels_gpu.py."""
     import copy
     from deadtrees_amd.loss.seg_loss import seg_loss
     from oracle.train_ref import loss_from_logits
+    from deadtrees_amd.data.distmap import distmaps_on_device
+    from oracle.losses_ref import dist_map, one_hot
     B, H, W = 2, 128, 128
-    ref, m = _pair()
+    ref, m = _pair(C, K)
     ref64 = copy.deepcopy(ref).double()
-    img, mask = _synth(B, H, W)
+    img, mask = _synth(B, H, W, C, K)
+    dist = None
+    if "BOUNDARY" in names:   # the reference loader's maps for the oracle; the HIP side builds its own on the device
+        oh = one_hot(mask, K).numpy()
+        dist = torch.from_numpy(np.stack([dist_map(oh[i]) for i in range(B)]).astype(np.float32))
     ref.train()
     ref64.train()
     m.train()
     logits_ref = ref(img)
-    loss_ref, _ = loss_from_logits(logits_ref, mask, ("GDICE", "FOCAL"))
+    loss_ref, _ = loss_from_logits(logits_ref, mask, names, dist)
     loss_ref.backward()
     logits64 = ref64(img.double())
-    loss64, _ = loss_from_logits(logits64, mask, ("GDICE", "FOCAL"))
+    loss64, _ = loss_from_logits(logits64, mask, names, None if dist is None else dist.double())
     loss64.backward()
     logits = m(img.to(DEV))
-    loss, parts, err = seg_loss(logits, mask.to(DEV), None, ("GDICE", "FOCAL"))
+    ddist = distmaps_on_device(mask.to(DEV), K) if dist is not None else None
+    if ddist is not None:
+        assert torch.equal(ddist.cpu(), dist)
+    loss, parts, err = seg_loss(logits, mask.to(DEV), ddist, names)
     loss.backward()
     assert int(err) == 0
     e_hip = float((logits.detach().cpu().double() - logits64.detach()).abs().max())
@@ -105,7 +117,7 @@ def test_train_step_gradient_parity():
         n = float(g.norm()) + 1e-30
         eh = float((grads[k].double() - g).norm())
         er = float((g32[k].double() - g).norm())
-        assert eh <= 3.0 * er + 1e-4 * n, (k, eh / n, er / n)
+        assert eh <= 4.0 * er + 1e-4 * n, (k, eh / n, er / n)   # per tensor: 4x the fp32 oracle's own error
         tot_hip += eh ** 2
         tot_ref += er ** 2
         tot += n ** 2
