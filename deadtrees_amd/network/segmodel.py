@@ -249,13 +249,24 @@ class SemSegment(_Base):
                 return super().load_from_checkpoint(path, map_location=map_location)
             except Exception:  # noqa: BLE001 - fall through to the plain format
                 pass
-        ck = torch.load(str(path), map_location=map_location, weights_only=True)
-        if "hyper_parameters_json" not in ck:
-            raise RuntimeError("Lightning checkpoints with pickled omegaconf hyper-parameters cannot be read without "
-                               "pytorch_lightning/omegaconf; re-save with SemSegment.save_checkpoint")
-        hp = json.loads(ck["hyper_parameters_json"])
-        m = cls(hp["network"], hp["training"])
-        m.model.load_smp_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items()})
+        try:
+            ck = torch.load(str(path), map_location=map_location, weights_only=True)
+        except Exception:  # noqa: BLE001 - pickled omegaconf / Lightning objects: weights_only refuses them
+            ck = None
+        if ck is not None and "hyper_parameters_json" in ck:
+            hp = json.loads(ck["hyper_parameters_json"])
+            m = cls(hp["network"], hp["training"])
+            m.model.load_smp_state_dict({k[len("model."):]: v for k, v in ck["state_dict"].items()})
+            return m
+        # a checkpoint written by the reference's Lightning trainer: tensors through the restricted reader (nothing
+        # in the file is imported or executed), network configuration from the tensor shapes, default training conf
+        from ..utils.ckpt import infer_network_conf, lightning_state_dict
+        from ..utils.config import default_training
+        sd = lightning_state_dict(path)
+        net = infer_network_conf(sd)
+        net["losses"] = ["GDICE", "FOCAL"]
+        m = cls(net, default_training())
+        m.model.load_smp_state_dict(sd)
         return m
 
 

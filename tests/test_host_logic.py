@@ -173,3 +173,85 @@ def test_distmap_matches_reference_golden(golden_dir):
         z = np.load(path)
         got = distmaps_for_batch(torch.from_numpy(z["mask"]), z["logits"].shape[1])
         np.testing.assert_array_equal(got.numpy(), z["distmap"])
+
+
+def test_restricted_lightning_checkpoint_reader(tmp_path):
+    """deadtrees_amd.utils.ckpt: a Lightning-style .ckpt that pickles objects of modules we do not have (the
+    reference's omegaconf hyper-parameters) and a hostile reduce is read without importing or running anything;
+    tensors come back bit-exact (incl. views with offsets / strides) and the network conf follows from the shapes."""
+    import sys
+    import types
+    from deadtrees_amd.utils import ckpt as C
+    from oracle.unet_ref import make_oracle
+    ref = make_oracle(4, 3, seed=5)
+    sd = {f"model.{k}": v for k, v in ref.state_dict().items()}
+    base = torch.arange(24, dtype=torch.float32)
+    sd["model.extra_view"] = base[4:].view(4, 5).t()            # offset + non-contiguous strides
+    fake = types.ModuleType("omegaconf_like")
+
+    class DictConfig(dict):
+        def __reduce__(self):
+            return (DictConfig, (), {"_content": dict(self), "_flags": None})
+
+        def __setstate__(self, st):
+            self.update(st["_content"])
+    DictConfig.__module__, DictConfig.__qualname__ = "omegaconf_like", "DictConfig"
+    fake.DictConfig = DictConfig
+    sys.modules["omegaconf_like"] = fake
+
+    class Boom:
+        def __reduce__(self):
+            return (os.system, (f"touch {tmp_path}/pwned",))
+    p = tmp_path / "lightning.ckpt"
+    try:
+        torch.save({"state_dict": sd, "epoch": 7, "hyper_parameters": DictConfig(network=DictConfig(a=1)),
+                    "callbacks": {"x": Boom()}}, str(p))
+    finally:
+        del sys.modules["omegaconf_like"]
+    with pytest.raises(Exception):
+        torch.load(str(p), weights_only=True)                   # what the plain safe loader does with such a file
+    ck = C.read_checkpoint_tensors(p)
+    assert not (tmp_path / "pwned").exists()                    # the reduce was never executed
+    assert ck["epoch"] == 7 and isinstance(ck["hyper_parameters"], C._Inert)
+    got = C.lightning_state_dict(p)
+    assert set(got) == {k[len("model."):] for k in sd}
+    for k, v in sd.items():
+        assert torch.equal(got[k[len("model."):]], v), k
+    got.pop("extra_view")
+    conf = C.infer_network_conf(got)
+    assert conf["in_channels"] == 4 and conf["classes"] == ["background", "conifers", "deciduous"]
+    assert conf["encoder_name"] == "resnet34"
+    with pytest.raises(RuntimeError):
+        (tmp_path / "junk.ckpt").write_bytes(b"not a zip")
+        C.read_checkpoint_tensors(tmp_path / "junk.ckpt")
+
+
+def test_semsegment_loads_reference_style_lightning_checkpoint(tmp_path):
+    """SemSegment.load_from_checkpoint on a file shaped like the reference's ModelCheckpoint output (state_dict under
+    'model.', pickled hyper-parameter objects of an absent package): weights arrive, conf inferred from shapes."""
+    import sys
+    import types
+    from deadtrees_amd.network.segmodel import SemSegment
+    from oracle.unet_ref import make_oracle
+    ref = make_oracle(3, 2, seed=9)
+    fake = types.ModuleType("omegaconf_like2")
+
+    class Cfg:
+        pass
+    Cfg.__module__, Cfg.__qualname__ = "omegaconf_like2", "Cfg"
+    fake.Cfg = Cfg
+    sys.modules["omegaconf_like2"] = fake
+    p = tmp_path / "bestmodel.ckpt"
+    try:
+        torch.save({"state_dict": {f"model.{k}": v for k, v in ref.state_dict().items()},
+                    "hyper_parameters": {"network": Cfg(), "training": Cfg()}, "pytorch-lightning_version": "1.5.0"},
+                   str(p))
+    finally:
+        del sys.modules["omegaconf_like2"]
+    m = SemSegment.load_from_checkpoint(p)
+    assert m.in_channels == 3 and m.model.spec.classes == 2
+    sd = m.model.state_dict()
+    for k, v in ref.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        assert torch.equal(sd[k].cpu(), v), k
