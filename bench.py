@@ -243,8 +243,17 @@ def infer_bench(args, model, dev, world, rank, distributed):
     u8 = synth_u8_batch(B, S, S, seed=99 + rank).to(dev)
     model.eval()
 
-    def step():
-        x = ops.normalize_u8(u8, MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
+    use_graph = args.graph == "on"      # measured: the eager inference leg is already GPU-bound (6.9 k vs 6.7 k tiles/s)
+    if use_graph:
+        from deadtrees_amd.deployment.inference import GraphedTilePredictor
+        graphed = GraphedTilePredictor(model, 3, args.precision)
+        graphed(u8)                                  # set-up (eager warm-up + capture), not a timed or warm-up step
+
+    def step(src=None):
+        src = u8 if src is None else src
+        if use_graph:
+            return graphed(src)
+        x = ops.normalize_u8(src, MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
         return model.predict_classes(x, dtype="uint8", precision=args.precision)
 
     for _ in range(args.warmup):
@@ -285,9 +294,8 @@ def infer_bench(args, model, dev, world, rank, distributed):
                     dev_in[k].copy_(host_in[k], non_blocking=True)
                     ev_in[k].record(copy)
                 main_s.wait_event(ev_in[k])
-                x = ops.normalize_u8(dev_in[k], MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
+                o = step(dev_in[k])
                 ev_free[k].record(main_s)
-                o = model.predict_classes(x, dtype="uint8", precision=args.precision)
                 host_out[k].copy_(o, non_blocking=True)
             torch.cuda.synchronize()
             pcie = B * n / (time.perf_counter() - t1)
@@ -303,7 +311,7 @@ def infer_bench(args, model, dev, world, rank, distributed):
            "km2_per_hour": round(tiles_s * km2_per_tile * 3600.0, 1),
            "whole_net": {"tflops": round(tiles_s / world * fwd_flop / 1e12, 2),
                          "mfma_frac": round(tiles_s / world * fwd_flop / 1e12 / PEAK_FP32_TFLOPS, 4)},
-           "foreground_pixels": int(out.sum()),
+           "foreground_pixels": int(out.sum()), "hip_graph": use_graph,
            "pcie_inclusive_tiles_per_s_per_gpu": None if pcie is None else round(pcie, 1)}
     if rank == 0:
         print(json.dumps(res), flush=True)

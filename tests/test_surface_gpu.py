@@ -277,3 +277,25 @@ def test_graph_replayed_training_equals_eager(precision):
     assert te == tg == 7
     assert le == lg, (le, lg)
     assert torch.equal(pe, pg) and torch.equal(me, mg) and torch.equal(ve, vg) and torch.equal(be, bg)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graphed_tile_predictor_equals_eager(precision):
+    """GraphedTilePredictor: uint8 tiles -> uint8 class maps through one HIP graph; bit-identical to the eager chain,
+    for changing inputs and two batch shapes."""
+    from deadtrees_amd import ops
+    from deadtrees_amd.data.synthetic import MEAN, STD, synth_u8_batch
+    from deadtrees_amd.deployment.inference import GraphedTilePredictor
+    from deadtrees_amd.network.unet import UNetHIP
+    from oracle.unet_ref import make_oracle
+    m = UNetHIP()
+    m.load_state_dict(make_oracle(3, 2, seed=2).state_dict())
+    m.to(DEV).eval()
+    gp = GraphedTilePredictor(m, 3, precision)
+    for seed, (B, S) in enumerate([(2, 128), (2, 128), (3, 64), (2, 128)]):
+        u8 = synth_u8_batch(B, S, S, seed=seed).to(DEV)
+        x = ops.normalize_u8(u8, MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
+        want = m.predict_classes(x, dtype="uint8", precision=precision)
+        got = gp(u8).clone()
+        assert torch.equal(got, want)
+    assert len(gp._graphs) == 2
