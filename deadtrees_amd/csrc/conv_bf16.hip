@@ -484,6 +484,61 @@ extern "C" int dt_pack_dgrad_weights_bf16(const float* w_hwio, void* out, int ks
   return DT_OK;
 }
 
+// ------------------------------------------------------------------ all weight images of a network in ONE launch
+// The per-layer pack / flip kernels above are 4-5 us each and there are ~45 layers: 90-135 launches per step.
+// Table-driven variant over the flat parameter buffer: row l = (w_off, taps, Cin, Cout, first_tile); a workgroup
+// owns one 32x32 (ci, co) tile of one tap.  mode 0: fp32 [tap'][co][ci] with reversed taps (dt_weight_flip_transpose),
+// 1: bf16 [tap][co][ci] (dt_pack_weights_bf16), 2: bf16 HWIO with reversed taps (dt_pack_dgrad_weights_bf16).
+// Images are written at the layer's own offset w_off of the output buffer.
+__global__ __launch_bounds__(256) void weight_images_kernel(const float* __restrict__ params, void* __restrict__ out,
+                                                            const int32_t* __restrict__ table, int n_layers, int mode) {
+  __shared__ float tile[32][33];
+  __shared__ int32_t row[5];
+  if (threadIdx.x == 0) {
+    int l = 0;
+    while (l + 1 < n_layers && table[(l + 1) * 5 + 4] <= (int)blockIdx.x) ++l;   // <= 64 layers: linear scan
+#pragma unroll
+    for (int k = 0; k < 5; ++k) row[k] = table[l * 5 + k];
+  }
+  __syncthreads();
+  const int w_off = row[0], taps = row[1], Cin = row[2], Cout = row[3];
+  const int t = (int)blockIdx.x - row[4];
+  const int cob = (Cout + 31) / 32, cib = (Cin + 31) / 32;
+  const int tap = t / (cib * cob), ci0 = ((t / cob) % cib) * 32, co0 = (t % cob) * 32;
+  const bool flip = mode != 1, transpose = mode != 2;
+  const float* w = params + w_off + (size_t)(flip ? taps - 1 - tap : tap) * Cin * Cout;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int ci = ci0 + i, co = co0 + tx;
+    tile[i][tx] = (ci < Cin && co < Cout) ? w[(size_t)ci * Cout + co] : 0.f;
+  }
+  __syncthreads();
+  const size_t obase = (size_t)w_off + (size_t)tap * Cin * Cout;
+  for (int i = ty; i < 32; i += 8) {
+    if (transpose) {
+      const int co = co0 + i, ci = ci0 + tx;
+      if (ci < Cin && co < Cout) {
+        const size_t o = obase + (size_t)co * Cin + ci;
+        if (mode == 0) reinterpret_cast<float*>(out)[o] = tile[tx][i];
+        else reinterpret_cast<__bf16*>(out)[o] = (__bf16)tile[tx][i];
+      }
+    } else {
+      const int ci = ci0 + i, co = co0 + tx;
+      if (ci < Cin && co < Cout) reinterpret_cast<__bf16*>(out)[obase + (size_t)ci * Cout + co] = (__bf16)tile[i][tx];
+    }
+  }
+}
+
+extern "C" int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles,
+                                int mode, void* stream) {
+  DT_REQUIRE(params && out && table && n_layers > 0 && total_tiles > 0 && mode >= 0 && mode <= 2,
+             "weight_images: bad args");
+  hipLaunchKernelGGL(weight_images_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, params, out,
+                     table, n_layers, mode);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ bf16 elementwise passes (inference leg)
 // out = act(y*scale + shift + res'), y fp32 (stem output) or bf16, res bf16 with optional affine, out bf16
 template <bool Y_F32>

@@ -248,6 +248,29 @@ class UNetEngine:
         return logits, (am64 if am64 is not None else am8)
 
     # ------------------------------------------------------------------ bf16 inference leg
+    def _weight_table(self, device):
+        """device table of the BatchNorm-ed convolutions except the stem for dt_weight_images:
+        (w_off, taps, Cin, Cout, first_tile) rows, built once per device"""
+        key = ("wtab", str(device))
+        tab = self._tables.get(key) if hasattr(self, "_tables") else None
+        if tab is None:
+            rows, tiles = [], 0
+            for c in self.spec.convs:
+                if c is self.spec.stem or c.bn_key is None:
+                    continue
+                rows.append([c.w_off, c.k * c.k, c.cin, c.cout, tiles])
+                tiles += c.k * c.k * ((c.cin + 31) // 32) * ((c.cout + 31) // 32)
+            tab = (torch.tensor(rows, dtype=torch.int32).to(device), len(rows), tiles)
+            if not hasattr(self, "_tables"):
+                self._tables = {}
+            self._tables[key] = tab
+        return tab
+
+    def _weight_images(self, params: torch.Tensor, out: torch.Tensor, mode: int):
+        tab, n, tiles = self._weight_table(params.device)
+        _lib.check(self.lib.dt_weight_images(_p(params), _p(out), _p(tab), n, tiles, mode, _stream()),
+                   "dt_weight_images")
+
     def _bf16_weights(self, params: torch.Tensor, dgrad: bool = False):
         """bf16 images of every conv weight except stem and head: [tap][Cout][Cin] for the forward convs, or the
         data-gradient image (HWIO with reversed taps).  Repacked when the flat parameter buffer changed: torch's
@@ -259,12 +282,7 @@ class UNetEngine:
         buf = self._ws.get(name)
         if buf is None or buf.device != params.device:
             buf = torch.empty(self.spec.n_params, dtype=torch.bfloat16, device=params.device)
-        fn = self.lib.dt_pack_dgrad_weights_bf16 if dgrad else self.lib.dt_pack_weights_bf16
-        for c in self.spec.convs:
-            if c is self.spec.stem or c.bn_key is None:
-                continue
-            _lib.check(fn(_p(params[c.w_off:c.w_off + c.w_size]), _p(buf[c.w_off:c.w_off + c.w_size]), c.k, c.cin,
-                          c.cout, _stream()), "dt_pack_weights_bf16")
+        self._weight_images(params, buf, 2 if dgrad else 1)     # every layer's image in one launch
         self._ws[name + "_key"], self._ws[name] = key, buf
         return buf
 
@@ -721,10 +739,7 @@ class UNetEngine:
     def _dgrad(self, c: ConvSpec, params, dy, B, Hin, Win, out0, out1=None, split=0, acc=False):
         """gradient wrt the conv's logical input [B,Hin,Win,cin] (before virtual upsample handling)."""
         Ho, Wo = dy.shape[1], dy.shape[2]
-        wd = self._buf("wd", c.w_size, device=dy.device)
-        st = _stream()
-        _lib.check(self.lib.dt_weight_flip_transpose(_p(params[c.w_off:c.w_off + c.w_size]), _p(wd), c.k, c.cin,
-                                                     c.cout, st), "dt_weight_flip_transpose")
+        wd = self._wd_all[c.w_off:c.w_off + c.w_size]     # flipped / transposed image, built at the start of backward
         pad = c.k - 1 - c.pad
         if c.stride == 1:
             desc = self._desc(B, Ho, Wo, c.cout, 0, 0, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
@@ -747,6 +762,9 @@ class UNetEngine:
         dev = dlogits.device
         st = _stream()
         dlogits = dlogits.contiguous()
+        # data-gradient weight images of every layer ([tap'][co][ci], taps reversed) in one launch
+        self._wd_all = self._buf("wd_all", sp.n_params, device=dev)
+        self._weight_images(params, self._wd_all, 0)
 
         # ---- head
         hd = sp.head

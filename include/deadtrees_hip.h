@@ -270,6 +270,14 @@ int dt_maxpool3x3s2_bwd_bf16(const void* dout, const uint8_t* argmax, void* dx, 
                              int C, void* stream);
 int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C, void* stream);
 
+/* Every weight image of a network in one launch, table-driven over the flat parameter buffer: table int32
+ * [n_layers][5] = (w_off, taps, Cin, Cout, first_tile) on the DEVICE, first_tile = running sum of
+ * taps*ceil(Cin/32)*ceil(Cout/32); total_tiles = that sum over all layers.  The image of layer l lands at out + w_off
+ * (in elements of the output type).  mode 0 = dt_weight_flip_transpose (fp32), 1 = dt_pack_weights_bf16,
+ * 2 = dt_pack_dgrad_weights_bf16. */
+int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles, int mode,
+                     void* stream);
+
 /* ------------------------------------------------------------------ optimiser (K22) */
 /* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
 int dt_sumsq_rows(int64_t n);
