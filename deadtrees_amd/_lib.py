@@ -29,6 +29,10 @@ class ConvDesc(C.Structure):
 
 _P = C.POINTER(ConvDesc)
 
+
+class BnBwdFuse(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("y", "mean", "invstd", "act_scale", "act_shift")]
+
 # name -> (restype, argtypes).  Must list every symbol of include/deadtrees_hip.h
 # (tests/test_abi.py cross-checks this table against the header).
 SIGNATURES = {
@@ -71,6 +75,7 @@ SIGNATURES = {
     "dt_augment_normalize_u8": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_float), C.POINTER(C.c_float), c_f]),
     "dt_augment_labels": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_conv2d_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_weight_images": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_ensemble_vote": (C.c_int, [c_f, C.c_int, I64, C.c_int, c_f, c_f, c_f, c_f]),
     "dt_signed_distmap_workspace": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),

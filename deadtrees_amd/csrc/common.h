@@ -60,7 +60,8 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
 // ---- 16-channel-granular kernels (conv_narrow.hip)
 extern "C" int dt_conv2d_n16_supported(const dt_conv_desc* d);
 int dt_conv2d_n16_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
-                         const float* in_scale, const float* in_shift, hipStream_t st);
+                         const float* in_scale, const float* in_shift, hipStream_t st,
+                         const dt_bn_bwd_fuse* fuse = nullptr);
 extern "C" int dt_conv2d_wgrad_n16_supported(const dt_conv_desc* d);
 int dt_wgrad_n16_cfg(const dt_conv_desc* d, int* ksplit, int* parts);
 int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* dy, float* ws, const float* in_scale,

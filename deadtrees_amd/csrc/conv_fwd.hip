@@ -28,6 +28,8 @@ struct ConvArgs {
   __bf16* out0_bf16;      // when set (bf16 training path, stem): out0 is written as bf16 instead (no split/accumulate)
   float* out1;
   float* stats;
+  // fused BatchNorm-backward reduction (dt_conv2d_bn_bwd): when bnb.y is set, `stats` receives sum g, sum g*xhat
+  dt_bn_bwd_fuse bnb;
   int B, Hin, Win, C0, C1, mode0;
   int Ho, Wo, Cout, cout_split, pad, accumulate;
   int tiles_x, tiles_y, n_tiles, P;
@@ -216,7 +218,8 @@ __device__ __forceinline__ void mma_chunk_zi(const float* __restrict__ lds_in, c
 }
 
 // narrow-input stride-1 layers (Cin <= 32: one or two chunks, no pipelining depth) run the CK=8 variant at
-// 3 waves/SIMD; everything else 2 waves/SIMD (measured per layer with scripts/bench_conv.py)
+// 3 waves/SIMD when TN = 32 (with 64 output channels per tile 168 VGPRs spill); everything else 2 waves/SIMD
+// (measured per layer with scripts/bench_conv.py)
 // Zero-insertion (transposed-conv) tiles, ZI = true: 3/4 of the zero-inserted input is structurally zero, so an
 // output pixel of parity class (py,px) only sees the taps with (py+kh-pad, px+kw-pad) both even: 1/2/2/4 of the
 // 9 taps (1x1: only the even/even class).  Each 32-pixel MFMA row tile is therefore built from pixels of ONE
@@ -241,7 +244,7 @@ __device__ __forceinline__ void tile_pixel(int wave, int mt, int m, int& row, in
 #define DT_TF_MAXC 512   // channels of source 0 that may carry a fused input transform
 
 template <int KS, int STRIDE, int TW, int TN, int CK, bool ZI = false, bool TF = false>
-__global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32) ? 3 : 2) void conv_fwd_kernel(const ConvArgs a) {
   static_assert(!ZI || (TW == 32 && STRIDE == 1), "zero-insertion tiles are 8 x 32");
   static_assert(!TF || (KS != 7 && !ZI), "input transform: regular tiles only");
   // TF: per-channel scale/shift of source 0 live in LDS (no registers held across the MFMA loop)
@@ -459,6 +462,14 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
       }
     }
     const bool nok = n < a.Cout;
+    const bool bnb = a.bnb.y != nullptr;   // uniform
+    float b_mu = 0.f, b_is = 0.f, b_sc = 0.f, b_sh = 0.f;
+    if (bnb && nok) {
+      b_mu = a.bnb.mean[n];
+      b_is = a.bnb.invstd[n];
+      b_sc = a.bnb.act_scale[n];
+      b_sh = a.bnb.act_shift[n];
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       size_t off[16];
@@ -479,6 +490,21 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8) ? 3 : 2) v
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (ok[i]) outp[off[i]] = acc[mt][j][i] + prev[i];
+      } else if (bnb) {
+        // BatchNorm-backward partial sums of the layer this gradient belongs to (its raw output y at the same
+        // positions; 128-byte rows like the stores): g = v * [relu mask], sum g and sum g * xhat
+        float yv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) yv[i] = ok[i] ? a.bnb.y[off[i]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (ok[i]) {
+            const float v = acc[mt][j][i];
+            const float g = (yv[i] * b_sc + b_sh) > 0.f ? v : 0.f;
+            s1[j] += g;
+            s2[j] += g * ((yv[i] - b_mu) * b_is);
+            outp[off[i]] = v;
+          }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -596,7 +622,7 @@ static int launch_tw_tn(const ConvArgs& a, const ConvCfg& c, hipStream_t st) {
 
 static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* w, float* out0,
                        float* out1, float* stats, const float* in_scale, const float* in_shift, void* out_bf16,
-                       void* stream);
+                       void* stream, const dt_bn_bwd_fuse* fuse = nullptr);
 
 extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const float* w,
                          float* out0, float* out1, float* stats, const float* in_scale, const float* in_shift,
@@ -604,9 +630,18 @@ extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* 
   return conv2d_impl(d, src0, src1, w, out0, out1, stats, in_scale, in_shift, nullptr, stream);
 }
 
+extern "C" int dt_conv2d_bn_bwd(const dt_conv_desc* d, const float* src0, const float* w, float* out0, float* red,
+                                const dt_bn_bwd_fuse* fuse, void* stream) {
+  DT_REQUIRE(d && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale && fuse->act_shift,
+             "conv_bn_bwd: null pointer");
+  DT_REQUIRE(d->ksize == 3 && d->stride == 1 && d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0 && d->accumulate == 0,
+             "conv_bn_bwd: plain 3x3 stride-1 data gradients only");
+  return conv2d_impl(d, src0, nullptr, w, out0, nullptr, red, nullptr, nullptr, nullptr, stream, fuse);
+}
+
 static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* w, float* out0,
                        float* out1, float* stats, const float* in_scale, const float* in_shift, void* out_bf16,
-                       void* stream) {
+                       void* stream, const dt_bn_bwd_fuse* fuse) {
   int rc = validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && w && out0, "conv: null pointer");
@@ -616,9 +651,10 @@ static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* sr
   DT_REQUIRE(in_scale == nullptr || (d->ksize == 3 && d->stride == 1 && d->mode0 != 2 && d->C0 <= DT_TF_MAXC),
              "conv: input transform needs a 3x3 stride-1 layer with C0 <= %d and no zero-insertion", DT_TF_MAXC);
   if (dt_conv2d_n16_supported(d))
-    return dt_conv2d_n16_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream);
+    return dt_conv2d_n16_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream, fuse);
   ConvCfg c = pick_cfg(d);
   ConvArgs a;
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr};
   a.src0 = src0; a.src1 = src1; a.w = w; a.out0 = out0; a.out1 = out1; a.stats = stats;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out0_bf16 = (__bf16*)out_bf16;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
@@ -634,7 +670,7 @@ static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* sr
     if (d->ksize == 1) return c.tn == 64 ? launch<1, 1, 32, 64, 16, true>(a, st) : launch<1, 1, 32, 32, 16, true>(a, st);
   }
   if (d->ksize == 3 && d->stride == 1)
-    return (d->C0 + d->C1 <= 32) ? launch_tw_tn<3, 1, 8>(a, c, st) : launch_tw_tn<3, 1, 16>(a, c, st);
+    return (d->C0 + d->C1 <= 32 && c.tn == 32) ? launch_tw_tn<3, 1, 8>(a, c, st) : launch_tw_tn<3, 1, 16>(a, c, st);
   if (d->ksize == 3 && d->stride == 2) return launch_tw_tn<3, 2, 8>(a, c, st);
   if (d->ksize == 1 && d->stride == 2) return launch_tw_tn<1, 2, 16>(a, c, st);
   if (d->ksize == 1 && d->stride == 1) return launch_tw_tn<1, 1, 16>(a, c, st);
@@ -706,6 +742,6 @@ extern "C" int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck
   }
   if (tw) *tw = c.tw;
   if (tn) *tn = d->ksize == 7 ? 64 : c.tn;
-  if (ck) *ck = d->ksize == 7 ? 4 : ((d->ksize == 3 && (d->stride == 2 || d->C0 + d->C1 <= 32)) ? 8 : 16);
+  if (ck) *ck = d->ksize == 7 ? 4 : ((d->ksize == 3 && (d->stride == 2 || (d->C0 + d->C1 <= 32 && c.tn == 32))) ? 8 : 16);
   return DT_OK;
 }

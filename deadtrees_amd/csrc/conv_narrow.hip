@@ -18,6 +18,7 @@ struct NarrowArgs {
   const float* w;      // [9][Cin][Cout]
   float* out;
   float* stats;        // [2][P][Cout] or null
+  dt_bn_bwd_fuse bnb;  // fused BatchNorm-backward reduction (see conv_fwd.hip): stats = sum g, sum g*xhat
   int B, Hin, Win, Cin, mode0, Ho, Wo, Cout, tiles_x, tiles_y, P;
 };
 
@@ -135,6 +136,14 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_n16_kernel(const NarrowArgs a
   // ---- epilogue: D col = lane&15 (channel), row = 4*(lane>>4) + reg (pixel within the M-tile)
   float s1 = 0.f, s2 = 0.f;
   const bool nok = m < a.Cout;
+  const bool bnb = a.bnb.y != nullptr;   // uniform
+  float b_mu = 0.f, b_is = 0.f, b_sc = 0.f, b_sh = 0.f;
+  if (bnb && nok) {
+    b_mu = a.bnb.mean[m];
+    b_is = a.bnb.invstd[m];
+    b_sc = a.bnb.act_scale[m];
+    b_sh = a.bnb.act_shift[m];
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int oy = oy0 + wave * 2 + (t >> 1);
@@ -143,9 +152,17 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_n16_kernel(const NarrowArgs a
       const int ox = ox0 + (t & 1) * 16 + 4 * kq + i;
       if (nok && oy < a.Ho && ox < a.Wo) {
         const float v = acc[t][i];
-        s1 += v;
-        s2 += v * v;
-        a.out[(((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + m] = v;
+        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + m;
+        if (bnb) {
+          const float yv = a.bnb.y[o];
+          const float g = (yv * b_sc + b_sh) > 0.f ? v : 0.f;
+          s1 += g;
+          s2 += g * ((yv - b_mu) * b_is);
+        } else {
+          s1 += v;
+          s2 += v * v;
+        }
+        a.out[o] = v;
       }
     }
   }
@@ -179,8 +196,9 @@ extern "C" int dt_conv2d_n16_supported(const dt_conv_desc* d) {
 int dt_conv2d_n16_rows(const dt_conv_desc* d) { return d->B * dt_cdiv(d->Ho, N16_TH) * dt_cdiv(d->Wo, N16_TW); }
 
 int dt_conv2d_n16_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
-                         const float* in_scale, const float* in_shift, hipStream_t st) {
+                         const float* in_scale, const float* in_shift, hipStream_t st, const dt_bn_bwd_fuse* fuse) {
   NarrowArgs a;
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr};
   a.src0 = src0; a.w = w; a.out = out; a.stats = stats; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->C0; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;

@@ -696,20 +696,25 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ backward units
     def _bn_bwd(self, c: ConvSpec, params, grads, bnws, dout, out_act, y, dres=None, dres_acc=False,
-                virtual_act=False):
-        """virtual_act: the activation was never stored; its ReLU mask is recomputed from y*scale+shift"""
+                virtual_act=False, reduced=None):
+        """virtual_act: the activation was never stored; its ReLU mask is recomputed from y*scale+shift.
+        reduced = (red, P): the partial sums were already produced by the data-gradient kernel that wrote `dout`
+        (`_dgrad_bn`), so the reduction pass over (dout, y) is skipped."""
         B, H, W, Cc = y.shape
         n_pix = B * H * W
         nb = self.spec.n_bn_channels
         mean = bnws[c.bn_off: c.bn_off + Cc]
         invstd = bnws[nb + c.bn_off: nb + c.bn_off + Cc]
         gamma = params[c.g_off:c.g_off + Cc]
-        P = self.lib.dt_bn_bwd_rows(n_pix, Cc)
-        red = self._buf("bn_red", self.lib.dt_bn_bwd_red_floats(n_pix, Cc), device=y.device)
         st = _stream()
         asc, ash = self._ss(c, bnws) if virtual_act else (None, None)
-        _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc), _p(ash),
-                                             _p(red), n_pix, Cc, st), "dt_bn_bwd_reduce")
+        if reduced is not None:
+            red, P = reduced
+        else:
+            P = self.lib.dt_bn_bwd_rows(n_pix, Cc)
+            red = self._buf("bn_red", self.lib.dt_bn_bwd_red_floats(n_pix, Cc), device=y.device)
+            _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc), _p(ash),
+                                                 _p(red), n_pix, Cc, st), "dt_bn_bwd_reduce")
         dy = torch.empty_like(y)
         _lib.check(self.lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(asc),
                                             _p(ash), _p(red), P,
@@ -735,6 +740,33 @@ class UNetEngine:
                                             _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
                                             _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                             _stream()), "dt_conv2d_wgrad")
+
+    def _dgrad_bn(self, c: ConvSpec, dy, B, H, W, out0, bn_conv: ConvSpec, y, bnws):
+        """stride-1 data gradient of conv `c` into out0 with the BatchNorm-backward reduction of `bn_conv` (the layer
+        whose raw output `y` has out0's shape, activation virtual) fused into the epilogue -> (red, P) for _bn_bwd"""
+        Cc = bn_conv.cout
+        assert c.stride == 1 and c.cin == Cc and tuple(y.shape) == tuple(out0.shape)
+        wd = self._wd_all[c.w_off:c.w_off + c.w_size]
+        desc = self._desc(B, H, W, c.cout, 0, 0, H, W, c.cin, c.k, 1, c.k - 1 - c.pad)
+        P = self.lib.dt_conv2d_stat_rows(C.byref(desc))
+        red = self._buf("bn_red_fused", self.lib.dt_bn_stats_floats(P, Cc), device=dy.device)
+        nb = self.spec.n_bn_channels
+        asc, ash = self._ss(bn_conv, bnws)
+        fuse = _lib.BnBwdFuse(_p(y), _p(bnws[bn_conv.bn_off: bn_conv.bn_off + Cc]),
+                              _p(bnws[nb + bn_conv.bn_off: nb + bn_conv.bn_off + Cc]), _p(asc), _p(ash))
+        prof = self.profile
+        if prof is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(self.lib.dt_conv2d_bn_bwd(C.byref(desc), _p(dy), _p(wd), _p(out0), _p(red), C.byref(fuse),
+                                             _stream()), "dt_conv2d_bn_bwd")
+        if prof is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            flops = 2.0 * desc.ksize ** 2 * desc.C0 * desc.Cout * desc.Ho * desc.Wo * desc.B
+            nbytes = 4.0 * desc.B * desc.Ho * desc.Wo * (desc.C0 + 2 * desc.Cout) + 4.0 * desc.ksize ** 2 * desc.C0 * desc.Cout
+            prof.append((self._conv_kernel_name(desc, False), flops, e0, e1, nbytes))
+        return red, P
 
     def _dgrad(self, c: ConvSpec, params, dy, B, Hin, Win, out0, out1=None, split=0, acc=False):
         """gradient wrt the conv's logical input [B,Hin,Win,cin] (before virtual upsample handling)."""
@@ -790,9 +822,9 @@ class UNetEngine:
             dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"], virtual_act=d["z2"] is None)
             self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty_like(d["y1"])
-            self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
+            red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, d["y1"], bnws)
             del dy2
-            dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, d["y1"], virtual_act=True)
+            dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, d["y1"], virtual_act=True, reduced=red1)
             del dz1
             x_ss = self._ss(sp.decoder[i - 1].conv2, bnws) if d["x_virtual"] else None
             self._wgrad(blk.conv1, grads, d["x"], d["skip"], 1, B, Hh, Ww, dy1, in_ss=x_ss)
@@ -839,9 +871,9 @@ class UNetEngine:
                     del gd
                 self._wgrad(blk.conv2, grads, r["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
                 dz1 = torch.empty_like(r["y1"])
-                self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
+                red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, r["y1"], bnws)
                 del dy2
-                dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, r["y1"], virtual_act=True)
+                dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, r["y1"], virtual_act=True, reduced=red1)
                 del dz1
                 self._wgrad(blk.conv1, grads, r["x"], None, 0, B, Hin, Win, dy1)
                 self._dgrad(blk.conv1, params, dy1, B, Hin, Win, gin, acc=gin_has)

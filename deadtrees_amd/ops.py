@@ -302,6 +302,23 @@ def confusion_matrix(pred, target, lu=None, K=2, counts=None):
     return counts, err
 
 
+def conv2d_bn_bwd(src0, w_hwio, y, mean, invstd, act_scale, act_shift):
+    """3x3 stride-1 conv (a data gradient) whose epilogue also produces the BatchNorm-backward partial sums of the
+    layer with raw output `y` (same shape as the result).  -> (out [B,H,W,Cout], red [2,P,Cout])"""
+    _gpu(src0, w_hwio, y, mean, invstd, act_scale, act_shift)
+    lib = _lib.load()
+    B, H, W, C0 = src0.shape
+    Cout = w_hwio.shape[-1]
+    d = conv_desc(B, H, W, C0, 0, 0, Cout, 3, 1, 1)
+    P = lib.dt_conv2d_stat_rows(C.byref(d))
+    red = torch.empty(lib.dt_bn_stats_floats(P, Cout), dtype=torch.float32, device=src0.device)
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=src0.device)
+    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift))
+    _lib.check(lib.dt_conv2d_bn_bwd(C.byref(d), _p(src0), _p(w_hwio.contiguous()), _p(out), _p(red), C.byref(fuse),
+                                    _st()), "dt_conv2d_bn_bwd")
+    return out, red[:2 * P * Cout].view(2, P, Cout)
+
+
 # ---- bf16 elementwise kernels (thin wrappers; the engine calls the C ABI directly with its own buffers)
 def bn_act_bf16(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
     """bf16 (or fp32) y [.., C] -> bf16 act(y*scale+shift + (res*rscale+rshift))"""

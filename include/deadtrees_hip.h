@@ -147,6 +147,22 @@ int dt_augment_normalize_u8(const uint8_t* src, float* dst, const int32_t* geo, 
                             int B, int H, int W, int Csrc, int Cdst, const float* mean, const float* std, void* stream);
 int dt_augment_labels(const int64_t* src, int64_t* dst, const int32_t* geo, int B, int H, int W, void* stream);
 
+/* Data gradient of a 3x3 stride-1 layer with the BatchNorm-backward REDUCTION of the layer it feeds fused into the
+ * epilogue (instead of a separate dt_bn_bwd_reduce pass over the tensor it has just written): out0 = conv(src0, w)
+ * like dt_conv2d (no concat / split / accumulate / upsample), and red[2][P][Cout] (P = dt_conv2d_stat_rows(desc))
+ * receives per workgroup  sum g  and  sum g * xhat  with  g = out0 * [y*act_scale + act_shift > 0],
+ * xhat = (y - mean) * invstd  — exactly what dt_bn_bwd_reduce computes from (dout = out0, y) with a virtual
+ * activation.  `red` must hold dt_bn_stats_floats(P, Cout) floats; pass it with P to dt_bn_bwd_apply. */
+typedef struct dt_bn_bwd_fuse {
+  const float* y;          /* raw conv output of the BatchNorm layer, same shape as out0 */
+  const float* mean;
+  const float* invstd;
+  const float* act_scale;  /* scale / shift of that BatchNorm (its ReLU mask is recomputed from y) */
+  const float* act_shift;
+} dt_bn_bwd_fuse;
+int dt_conv2d_bn_bwd(const dt_conv_desc* desc, const float* src0, const float* w, float* out0, float* red,
+                     const dt_bn_bwd_fuse* fuse, void* stream);
+
 /* ------------------------------------------------------------------ segmentation head (K11,K12,K19) */
 /* logits[B,K,H,W] (NCHW) = conv3x3(x[B,H,W,Cin], w[K][3][3][Cin]) + bias; optional uint8/int64 argmax
  * class map (ties -> lowest index, torch.argmax) — smp SegmentationHead + inference.py:62. */

@@ -24,6 +24,7 @@ SHAPES = [
     ("dec3.c2 32->32 @256", 256, 256, 32, 0, 0, 32, 3, 1, 1),
     ("dec4.c1 up32->16 @512", 256, 256, 32, 0, 1, 16, 3, 1, 1),
     ("dec4.c2 16->16 @512", 512, 512, 16, 0, 0, 16, 3, 1, 1),
+    ("dec3.c1 dgrad 32->128 @256", 256, 256, 32, 0, 0, 128, 3, 1, 1),
 ]
 only = os.environ.get("ONLY")
 which = os.environ.get("WHICH", "fwd,wgrad").split(",")

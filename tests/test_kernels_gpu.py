@@ -313,3 +313,32 @@ def test_flat_adam_matches_torch():
         norm = fa.step(grad.to(DEV))
         assert float(norm) == pytest.approx(float(grad.norm()), rel=1e-5)
     assert rel_err(pg.cpu(), ref_p.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 40, 64, 64), (1, 24, 40, 16, 16), (2, 20, 36, 32, 32),
+                                            (2, 9, 70, 128, 96), (1, 33, 17, 64, 128)])
+def test_conv_with_fused_bn_backward_reduction(B, H, W, Cin, Cout):
+    """dt_conv2d_bn_bwd: output bit-identical to dt_conv2d; the partial sums equal the BatchNorm-backward
+    reduction (sum g, sum g*xhat with the ReLU mask recomputed from y) of dt_bn_bwd_reduce / fp64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 7 + Cin + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    y = torch.randn((B, Cout, H, W), generator=g) * 1.5 + 0.2
+    mean = y.mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(y.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    gamma, beta = 1 + 0.2 * torch.randn(Cout, generator=g), 0.2 * torch.randn(Cout, generator=g)
+    sc, sh = gamma * invstd, beta - mean * gamma * invstd
+    xg, wg, yg = nhwc(x), hwio(w), nhwc(y)
+    plain, _, _ = ops.conv2d(xg, wg, 3, 1, 1)
+    out, red = ops.conv2d_bn_bwd(xg, wg, yg, mean.to(DEV), invstd.to(DEV), sc.to(DEV), sh.to(DEV))
+    assert torch.equal(out, plain)
+    dz = to_nchw(out)
+    y64 = y.double()
+    mask = (y64.float() * sc[None, :, None, None] + sh[None, :, None, None]) > 0      # fp32 like the kernel
+    gm = torch.where(mask, dz, torch.zeros_like(dz))
+    xh = (y64 - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    sums = red.sum(dim=1).cpu().double()
+    scale = float(gm.abs().sum(dim=(0, 2, 3)).max()) + 1.0
+    assert float((sums[0] - gm.sum(dim=(0, 2, 3))).abs().max()) <= 2e-5 * scale
+    assert float((sums[1] - (gm * xh).sum(dim=(0, 2, 3))).abs().max()) <= 6e-5 * scale
