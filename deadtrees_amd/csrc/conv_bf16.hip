@@ -24,6 +24,9 @@ struct ConvBfArgs {
   __bf16* out;
   __bf16* out1;     // channels >= cout_split (decoder concat data gradient)
   float* stats;     // [2][P][Cout] BatchNorm partial sums from the fp32 accumulators, or null
+  // fused BatchNorm-backward reduction (dt_conv2d_bf16_bn_bwd): bnb.y (bf16, shape of `out`) set -> `stats` receives
+  // sum g, sum g*xhat of the layer this data gradient belongs to instead of sum v, sum v^2
+  dt_bn_bwd_fuse bnb;
   int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, n_tiles, P, cout_split, accumulate;
 };
 
@@ -225,6 +228,24 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
   const bool join = a.accumulate && !second;
   constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS;
   const int seg = tid % SEGS, prow = tid / SEGS;
+  const bool bnb = a.bnb.y != nullptr && !join;   // uniform
+  float q1[8], q2[8], b_mu[8], b_is[8], b_sc[8], b_sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q1[k] = q2[k] = b_mu[k] = b_is[k] = b_sc[k] = b_sh[k] = 0.f;
+  if (bnb && n0 + 8 * seg < a.Cout) {
+    auto ld8 = [&](const float* p, float (&v)[8]) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(p + n0 + 8 * seg), hi = *reinterpret_cast<const f32x4*>(p + n0 + 8 * seg + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = lo[k];
+        v[4 + k] = hi[k];
+      }
+    };
+    ld8(a.bnb.mean, b_mu);
+    ld8(a.bnb.invstd, b_is);
+    ld8(a.bnb.act_scale, b_sc);
+    ld8(a.bnb.act_shift, b_sh);
+  }
   // the tile is written out in slices of 256 pixels (MT / 2 of them) through the same staging image
 #pragma unroll
   for (int sl = 0; sl < MT / 2; ++sl) {
@@ -253,9 +274,25 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
         for (int it = 0; it < SEGS; ++it) {
           const int pl = prow + it * PER_IT;
           const int oy = oy0 + (pbase + pl) / TW, ox = ox0 + (pbase + pl) % TW;
-          if (oy < a.Ho && ox < a.Wo)
-            *reinterpret_cast<f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) =
-                *reinterpret_cast<const f32x4*>(lds + pl * OUT_PITCH + 8 * seg);
+          if (oy < a.Ho && ox < a.Wo) {
+            const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg;
+            const f32x4 raw = *reinterpret_cast<const f32x4*>(lds + pl * OUT_PITCH + 8 * seg);
+            *reinterpret_cast<f32x4*>(outp + o) = raw;
+            if (bnb) {
+              // BatchNorm-backward partial sums from the ROUNDED gradient and the layer's raw output y, with the ReLU
+              // mask the consumers saw (sign of bf16(y*sc+sh)) — the arithmetic of bn_bwd_reduce_bf16_kernel
+              const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + o);
+              const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&raw), yv = *reinterpret_cast<const bf16x8*>(&yraw);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float yk = (float)yv[k];
+                const float act = (float)(__bf16)(yk * b_sc[k] + b_sh[k]);
+                const float g = act > 0.f ? (float)gv[k] : 0.f;
+                q1[k] += g;
+                q2[k] += g * ((yk - b_mu[k]) * b_is[k]);
+              }
+            }
+          }
         }
       }
     } else {
@@ -301,7 +338,26 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs 
       }
     }
   }
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr && bnb) {
+    // per-thread sums over its pixels of 8 channels -> per-channel sums over the 256 / SEGS threads of a segment
+    __syncthreads();
+    float* qs = reinterpret_cast<float*>(lds);   // [2][8][256]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      qs[k * 256 + tid] = q1[k];
+      qs[(8 + k) * 256 + tid] = q2[k];
+    }
+    __syncthreads();
+    if (tid < 2 * TN) {
+      const int which = tid / TN, c = tid % TN;
+      if (n0 + c < a.Cout) {
+        const float* col = qs + (which * 8 + (c & 7)) * 256 + (c >> 3);
+        float sum = 0.f;
+        for (int i = 0; i < PER_IT; ++i) sum += col[i * SEGS];   // fixed order
+        a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = sum;
+      }
+    }
+  } else if (a.stats != nullptr) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds);  // [2][4 waves][TN]
 #pragma unroll
@@ -408,9 +464,30 @@ extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
   return d->B * dt_cdiv(d->Ho, 128 * mt / tw) * dt_cdiv(d->Wo, tw);
 }
 
+static int conv2d_bf16_impl(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16, void* out,
+                            void* out1, float* stats, const float* in_scale, const float* in_shift, void* stream,
+                            const dt_bn_bwd_fuse* fuse);
+
 extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16,
                               void* out, void* out1, float* stats, const float* in_scale, const float* in_shift,
                               void* stream) {
+  return conv2d_bf16_impl(d, src0, src1, w_bf16, out, out1, stats, in_scale, in_shift, stream, nullptr);
+}
+
+extern "C" int dt_conv2d_bf16_bn_bwd(const dt_conv_desc* d, const void* src0, const void* w_bf16, void* out, float* red,
+                                     const dt_bn_bwd_fuse* fuse, void* stream) {
+  DT_REQUIRE(d && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale && fuse->act_shift,
+             "conv_bf16_bn_bwd: null pointer");
+  DT_REQUIRE(d->ksize == 3 && d->stride == 1 && d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0 && d->accumulate == 0,
+             "conv_bf16_bn_bwd: plain 3x3 stride-1 data gradients only");
+  DT_REQUIRE((((uintptr_t)fuse->mean | (uintptr_t)fuse->invstd | (uintptr_t)fuse->act_scale |
+               (uintptr_t)fuse->act_shift) & 15) == 0, "conv_bf16_bn_bwd: per-channel arrays must be 16-byte aligned");
+  return conv2d_bf16_impl(d, src0, nullptr, w_bf16, out, nullptr, red, nullptr, nullptr, stream, fuse);
+}
+
+static int conv2d_bf16_impl(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16, void* out,
+                            void* out1, float* stats, const float* in_scale, const float* in_shift, void* stream,
+                            const dt_bn_bwd_fuse* fuse) {
   int rc = bf_validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && w_bf16 && out, "conv_bf16: null pointer");
@@ -421,6 +498,7 @@ extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const voi
   int tw, tn, ck, mt;
   bf_cfg(d, &tw, &tn, &ck, &mt);
   ConvBfArgs a;
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr};
   a.out1 = (__bf16*)out1; a.stats = stats; a.cout_split = d->cout_split; a.accumulate = d->accumulate;
   a.src0 = (const __bf16*)src0; a.src1 = (const __bf16*)src1; a.w = (const __bf16*)w_bf16;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out = (__bf16*)out;

@@ -550,16 +550,19 @@ class UNetEngine:
         wbd = self._bf16_weights(params, dgrad=True)
         nb = sp.n_bn_channels
 
-        def bn_bwd(c, dout, out_act, y, dres=None, dres_acc=False, virtual_act=False):
+        def bn_bwd(c, dout, out_act, y, dres=None, dres_acc=False, virtual_act=False, reduced=None):
             Bq, Hq, Wq, Cq = y.shape
             n_pix = Bq * Hq * Wq
-            P = lib.dt_bn_bwd_rows_bf16(n_pix)
-            red = self._buf("bn_red", lib.dt_bn_stats_floats(P, Cq), device=dev)
             mean = bnws[c.bn_off:c.bn_off + Cq]
             invstd = bnws[nb + c.bn_off:nb + c.bn_off + Cq]
             asc, ash = self._ss(c, bnws) if virtual_act else (None, None)
-            _lib.check(lib.dt_bn_bwd_reduce_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc), _p(ash),
-                                                 _p(red), n_pix, Cq, st), "dt_bn_bwd_reduce_bf16")
+            if reduced is not None:       # partial sums came out of the data-gradient kernel that wrote dout
+                red, P = reduced
+            else:
+                P = lib.dt_bn_bwd_rows_bf16(n_pix)
+                red = self._buf("bn_red", lib.dt_bn_stats_floats(P, Cq), device=dev)
+                _lib.check(lib.dt_bn_bwd_reduce_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc),
+                                                     _p(ash), _p(red), n_pix, Cq, st), "dt_bn_bwd_reduce_bf16")
             dy = torch.empty(y.shape, dtype=bf, device=dev)
             _lib.check(lib.dt_bn_bwd_apply_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd),
                                                 _p(params[c.g_off:c.g_off + Cq]), _p(asc), _p(ash), _p(red), P,
@@ -584,6 +587,20 @@ class UNetEngine:
                                                 _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
                                                 _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                                 _stream()), "dt_conv2d_wgrad_bf16")
+
+        def dgrad_bn(c, dy, Hh, Ww, out0, bn_conv, y):
+            """stride-1 data gradient of conv c with the BatchNorm-backward reduction of bn_conv fused (fp32 twin:
+            _dgrad_bn) -> (red, P)"""
+            Cq = bn_conv.cout
+            desc = self._desc(B, Hh, Ww, c.cout, 0, 0, Hh, Ww, c.cin, c.k, 1, c.k - 1 - c.pad)
+            P = lib.dt_conv2d_bf16_stat_rows(C.byref(desc))
+            red = self._buf("bn_red_fused", lib.dt_bn_stats_floats(P, Cq), device=dev)
+            asc, ash = self._ss(bn_conv, bnws)
+            fuse = _lib.BnBwdFuse(_p(y), _p(bnws[bn_conv.bn_off:bn_conv.bn_off + Cq]),
+                                  _p(bnws[nb + bn_conv.bn_off:nb + bn_conv.bn_off + Cq]), _p(asc), _p(ash))
+            _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(desc), _p(dy), _p(wbd[c.w_off:c.w_off + c.w_size]), _p(out0),
+                                                 _p(red), C.byref(fuse), _stream()), "dt_conv2d_bf16_bn_bwd")
+            return red, P
 
         def dgrad(c, dy, Hin, Win, out0, out1=None, split=0, acc=False):
             Ho, Wo = dy.shape[1], dy.shape[2]
@@ -614,9 +631,9 @@ class UNetEngine:
             dy2 = bn_bwd(blk.conv2, g, d["z2"], d["y2"], virtual_act=d["z2"] is None)
             wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty(d["y1"].shape, dtype=bf, device=dev)
-            dgrad(blk.conv2, dy2, Hh, Ww, dz1)
+            red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, d["y1"])
             del dy2
-            dy1 = bn_bwd(blk.conv1, dz1, None, d["y1"], virtual_act=True)
+            dy1 = bn_bwd(blk.conv1, dz1, None, d["y1"], virtual_act=True, reduced=red1)
             del dz1
             x_ss = self._ss(sp.decoder[i - 1].conv2, bnws) if d["x_virtual"] else None
             wgrad(blk.conv1, d["x"], d["skip"], 1, Hh, Ww, dy1, in_ss=x_ss)
@@ -658,9 +675,9 @@ class UNetEngine:
                     del gd
                 wgrad(blk.conv2, r["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
                 dz1 = torch.empty(r["y1"].shape, dtype=bf, device=dev)
-                dgrad(blk.conv2, dy2, Hh, Ww, dz1)
+                red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, r["y1"])
                 del dy2
-                dy1 = bn_bwd(blk.conv1, dz1, None, r["y1"], virtual_act=True)
+                dy1 = bn_bwd(blk.conv1, dz1, None, r["y1"], virtual_act=True, reduced=red1)
                 del dz1
                 wgrad(blk.conv1, r["x"], None, 0, Hin, Win, dy1)
                 dgrad(blk.conv1, dy1, Hin, Win, gin, acc=gin_has)

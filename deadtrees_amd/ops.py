@@ -319,6 +319,21 @@ def conv2d_bn_bwd(src0, w_hwio, y, mean, invstd, act_scale, act_shift):
     return out, red[:2 * P * Cout].view(2, P, Cout)
 
 
+def conv2d_bf16_bn_bwd(src0, w_packed, cout, y, mean, invstd, act_scale, act_shift):
+    """bf16 twin of conv2d_bn_bwd (src0, y bf16 NHWC; w_packed from pack_weights_bf16) -> (out bf16, red [2,P,Cout])"""
+    _gpu(src0, w_packed, y, mean, invstd, act_scale, act_shift)
+    lib = _lib.load()
+    B, H, W, C0 = src0.shape
+    d = conv_desc(B, H, W, C0, 0, 0, cout, 3, 1, 1)
+    P = lib.dt_conv2d_bf16_stat_rows(C.byref(d))
+    red = torch.empty(lib.dt_bn_stats_floats(P, cout), dtype=torch.float32, device=src0.device)
+    out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=src0.device)
+    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift))
+    _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(d), _p(src0), _p(w_packed), _p(out), _p(red), C.byref(fuse), _st()),
+               "dt_conv2d_bf16_bn_bwd")
+    return out, red[:2 * P * cout].view(2, P, cout)
+
+
 # ---- bf16 elementwise kernels (thin wrappers; the engine calls the C ABI directly with its own buffers)
 def bn_act_bf16(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
     """bf16 (or fp32) y [.., C] -> bf16 act(y*scale+shift + (res*rscale+rshift))"""

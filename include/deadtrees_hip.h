@@ -294,6 +294,12 @@ int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C
 int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles, int mode,
                      void* stream);
 
+/* bf16 twin of dt_conv2d_bn_bwd: fuse->y points at the bf16 raw output of the BatchNorm layer (cast to const
+ * float*); the sums use the rounded bf16 gradient and the mask of bf16(y*scale+shift), like dt_bn_bwd_reduce_bf16.
+ * P = dt_conv2d_bf16_stat_rows(desc). */
+int dt_conv2d_bf16_bn_bwd(const dt_conv_desc* desc, const void* src0, const void* w_bf16, void* out, float* red,
+                          const dt_bn_bwd_fuse* fuse, void* stream);
+
 /* ------------------------------------------------------------------ optimiser (K22) */
 /* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
 int dt_sumsq_rows(int64_t n);

@@ -273,3 +273,32 @@ def test_maxpool_and_upsample_backward_bf16():
     got = ops.upsample2x_bwd_bf16(up.to(DEV))
     want_up = up.double().reshape(2, 12, 2, 10, 2, 32).sum(dim=(2, 4))
     close_bf16(got.cpu().double(), want_up)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 40, 64, 64), (1, 24, 40, 16, 16), (2, 20, 36, 32, 32),
+                                            (2, 9, 70, 128, 96), (16, 120, 128, 48, 128)])
+def test_conv_bf16_with_fused_bn_backward_reduction(B, H, W, Cin, Cout):
+    """dt_conv2d_bf16_bn_bwd: output bit-identical to dt_conv2d_bf16; partial sums = BatchNorm-backward reduction of
+    the rounded gradient with the mask of bf16(y*scale+shift) (what dt_bn_bwd_reduce_bf16 computes)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 7 + Cin + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g).to(BF)
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(BF)
+    y = (torch.randn((B, Cout, H, W), generator=g) * 1.5 + 0.2).to(BF)
+    mean = y.float().mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(y.float().var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    gamma, beta = 1 + 0.2 * torch.randn(Cout, generator=g), 0.2 * torch.randn(Cout, generator=g)
+    sc, sh = gamma * invstd, beta - mean * gamma * invstd
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)  # noqa: E731
+    wp = ops.pack_weights_bf16(w.float().permute(2, 3, 1, 0).contiguous().to(DEV))
+    plain, _, _ = ops.conv2d_bf16(nh(x), wp, 3, 1, 1, Cout)
+    out, red = ops.conv2d_bf16_bn_bwd(nh(x), wp, Cout, nh(y), mean.to(DEV), invstd.to(DEV), sc.to(DEV), sh.to(DEV))
+    assert torch.equal(out, plain)
+    dz = out.float().cpu().permute(0, 3, 1, 2).double()
+    act = (y.float() * sc[None, :, None, None] + sh[None, :, None, None]).to(BF).float()
+    gm = torch.where(act > 0, dz, torch.zeros_like(dz))
+    xh = (y.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    sums = red.sum(dim=1).cpu().double()
+    scale = float(gm.abs().sum(dim=(0, 2, 3)).max()) + 1.0
+    assert float((sums[0] - gm.sum(dim=(0, 2, 3))).abs().max()) <= 3e-5 * scale
+    assert float((sums[1] - (gm * xh).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * scale
