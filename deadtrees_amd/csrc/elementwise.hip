@@ -561,6 +561,78 @@ extern "C" int dt_upsample2x_bwd(const float* dup, float* dx, int accumulate, in
   return DT_OK;
 }
 
+// The same 2x2 sum with the BatchNorm-backward reduction of the layer that produced the (virtual) activation fused in:
+// g is the gradient of relu(bn(y)); the pass that writes g also accumulates sum g*mask and sum g*mask*xhat from the
+// layer's raw output y, so the separate dt_bn_bwd_reduce over (g, y) disappears.  One partial row per workgroup.
+__global__ __launch_bounds__(256) void upsample2x_bwd_bn_kernel(const f32x4* __restrict__ dup, f32x4* __restrict__ dx,
+                                                                const f32x4* __restrict__ y,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ act_scale,
+                                                                const float* __restrict__ act_shift,
+                                                                float* __restrict__ red, int B, int H, int W, int C4,
+                                                                int P) {
+  __shared__ f32x4 sh[2][256];
+  const int64_t total = (int64_t)B * H * W * C4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;   // multiple of C4 (host check): fixed channel quad
+  const int W2 = 2 * W, t = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + t;
+  const int c4 = (int)(i0 % C4);
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+  const f32x4 asc = reinterpret_cast<const f32x4*>(act_scale)[c4], ash = reinterpret_cast<const f32x4*>(act_shift)[c4];
+  f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sx = sg;
+  for (int64_t i = i0; i < total; i += stride) {
+    int64_t r = i / C4;
+    const int x = (int)(r % W);
+    r /= W;
+    const int yy = (int)(r % H);
+    const int b = (int)(r / H);
+    const int64_t base = (((int64_t)b * 2 * H + 2 * yy) * W2 + 2 * x) * C4 + c4;
+    f32x4 g = (dup[base] + dup[base + C4]) + (dup[base + (int64_t)W2 * C4] + dup[base + (int64_t)W2 * C4 + C4]);
+    dx[i] = g;
+    const f32x4 yv = y[i];
+    const f32x4 a = yv * asc + ash;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
+    sg += g;
+    sx += g * ((yv - mu) * is);
+  }
+  sh[0][t] = sg;
+  sh[1][t] = sx;
+  __syncthreads();
+  const int rl = t / C4, RL = 256 / C4;     // threads t, t + C4, ... share the channel quad
+  for (int s = RL >> 1; s >= 1; s >>= 1) {
+    if (rl < s) {
+      sh[0][t] += sh[0][t + s * C4];
+      sh[1][t] += sh[1][t + s * C4];
+    }
+    __syncthreads();
+  }
+  if (t < C4) {
+    reinterpret_cast<f32x4*>(red)[(size_t)blockIdx.x * C4 + t] = sh[0][t];
+    reinterpret_cast<f32x4*>(red)[((size_t)P + blockIdx.x) * C4 + t] = sh[1][t];
+  }
+}
+
+extern "C" int dt_upsample2x_bwd_bn_rows(int B, int H, int W, int C) {
+  return ew_grid((int64_t)B * H * W * (C / 4));
+}
+
+extern "C" int dt_upsample2x_bwd_bn(const float* dup, float* dx, const dt_bn_bwd_fuse* fuse, float* red, int B, int H,
+                                    int W, int C, void* stream) {
+  DT_REQUIRE(dup && dx && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale && fuse->act_shift &&
+                 B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0,
+             "upsample2x_bwd_bn: bad args");
+  const int C4 = C / 4;
+  DT_REQUIRE(C4 <= 256 && 256 % C4 == 0, "upsample2x_bwd_bn: C/4 must divide 256 (C=%d)", C);
+  const int P = dt_upsample2x_bwd_bn_rows(B, H, W, C);
+  hipLaunchKernelGGL(upsample2x_bwd_bn_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dup,
+                     (f32x4*)dx, (const f32x4*)fuse->y, fuse->mean, fuse->invstd, fuse->act_scale, fuse->act_shift, red,
+                     B, H, W, C4, P);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ layout shuttles
 // NCHW <-> NHWC for small C (image: 3/4 channels; logits: K): one thread per pixel, planar side coalesced.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,

@@ -406,6 +406,98 @@ extern "C" int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, i
   return DT_OK;
 }
 
+// 2x2 sum + BatchNorm-backward reduction of the producing layer (bf16 twin of upsample2x_bwd_bn_kernel): sums from the
+// ROUNDED gradient and the mask of bf16(y*scale+shift), like bn_bwd_reduce_bf16_kernel
+__global__ __launch_bounds__(256) void upsample2x_bwd_bn_bf16_kernel(const bf16x8* __restrict__ dup, bf16x8* __restrict__ dx,
+                                                                     const bf16x8* __restrict__ y,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     const float* __restrict__ act_scale,
+                                                                     const float* __restrict__ act_shift,
+                                                                     float* __restrict__ red, int B, int H, int W, int C8,
+                                                                     int P) {
+  __shared__ float sh[16][256];
+  const int64_t total = (int64_t)B * H * W * C8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;   // multiple of C8 (host check)
+  const int W2 = 2 * W, t = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + t;
+  const int c8 = (int)(i0 % C8);
+  float mu[8], is[8], asc[8], ash[8], sg[8], sx[8];
+  ldc8(mean, c8 * 8, mu);
+  ldc8(invstd, c8 * 8, is);
+  ldc8(act_scale, c8 * 8, asc);
+  ldc8(act_shift, c8 * 8, ash);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sg[k] = sx[k] = 0.f;
+  for (int64_t i = i0; i < total; i += stride) {
+    int64_t rr = i / C8;
+    const int x = (int)(rr % W);
+    rr /= W;
+    const int yy = (int)(rr % H);
+    const int b = (int)(rr / H);
+    const int64_t base = (((int64_t)b * 2 * H + 2 * yy) * W2 + 2 * x) * C8 + c8;
+    float a[8], bq[8], c[8], d[8], yv[8];
+    load8(dup, base, a);
+    load8(dup, base + C8, bq);
+    load8(dup, base + (int64_t)W2 * C8, c);
+    load8(dup, base + (int64_t)W2 * C8 + C8, d);
+    load8(y, i, yv);
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = (__bf16)((a[k] + bq[k]) + (c[k] + d[k]));
+      const float act = (float)(__bf16)(yv[k] * asc[k] + ash[k]);
+      const float g = act > 0.f ? (float)o[k] : 0.f;
+      sg[k] += g;
+      sx[k] += g * ((yv[k] - mu[k]) * is[k]);
+    }
+    dx[i] = o;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sh[k][t] = sg[k];
+    sh[8 + k][t] = sx[k];
+  }
+  __syncthreads();
+  const int rl = t / C8, RL = 256 / C8;
+  for (int s = RL >> 1; s >= 1; s >>= 1) {
+    if (rl < s) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sh[k][t] += sh[k][t + s * C8];
+    }
+    __syncthreads();
+  }
+  if (t < C8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[(size_t)blockIdx.x * C8 * 8 + t * 8 + k] = sh[k][t];
+      red[((size_t)P + blockIdx.x) * C8 * 8 + t * 8 + k] = sh[8 + k][t];
+    }
+  }
+}
+
+extern "C" int dt_upsample2x_bwd_bn_bf16_rows(int B, int H, int W, int C) {
+  int64_t g = ((int64_t)B * H * W * (C / 8) + 255) / 256;
+  return (int)(g > 4096 ? 4096 : (g > 0 ? g : 1));
+}
+
+extern "C" int dt_upsample2x_bwd_bn_bf16(const void* dup, void* dx, const dt_bn_bwd_fuse* fuse, float* red, int B, int H,
+                                         int W, int C, void* stream) {
+  DT_REQUIRE(dup && dx && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale && fuse->act_shift &&
+                 B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0,
+             "upsample2x_bwd_bn_bf16: bad args");
+  const int C8 = C / 8;
+  DT_REQUIRE(C8 <= 256 && 256 % C8 == 0, "upsample2x_bwd_bn_bf16: C/8 must divide 256 (C=%d)", C);
+  DT_REQUIRE((((uintptr_t)fuse->mean | (uintptr_t)fuse->invstd | (uintptr_t)fuse->act_scale |
+               (uintptr_t)fuse->act_shift) & 15) == 0, "upsample2x_bwd_bn_bf16: per-channel arrays must be 16-byte aligned");
+  const int P = dt_upsample2x_bwd_bn_bf16_rows(B, H, W, C);
+  hipLaunchKernelGGL(upsample2x_bwd_bn_bf16_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dup,
+                     (bf16x8*)dx, (const bf16x8*)fuse->y, fuse->mean, fuse->invstd, fuse->act_scale, fuse->act_shift, red,
+                     B, H, W, C8, P);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ fp32 -> bf16
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const f32x4* __restrict__ x, bf16x8* __restrict__ out,
                                                           int64_t n8) {

@@ -625,10 +625,11 @@ class UNetEngine:
                                             _p(grads[hd.b_off:hd.b_off + K]), hd.cin, K, st), "dt_head_bwd_finalize")
 
         skip_grads = [None] * 5
+        g_red = None
         for i in range(4, -1, -1):
             blk, d = sp.decoder[i], S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
-            dy2 = bn_bwd(blk.conv2, g, d["z2"], d["y2"], virtual_act=d["z2"] is None)
+            dy2 = bn_bwd(blk.conv2, g, d["z2"], d["y2"], virtual_act=d["z2"] is None, reduced=g_red)
             wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty(d["y1"].shape, dtype=bf, device=dev)
             red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, d["y1"])
@@ -647,7 +648,21 @@ class UNetEngine:
                 dgrad(blk.conv1, dy1, Hh, Ww, dup)
             del dy1
             g = torch.empty(d["x"].shape, dtype=bf, device=dev)
-            _lib.check(lib.dt_upsample2x_bwd_bf16(_p(dup), _p(g), B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd_bf16")
+            g_red = None
+            if i >= 1 and d["x_virtual"]:
+                pb = sp.decoder[i - 1].conv2
+                y2p = S[f"D{i - 1}"]["y2"]
+                P = lib.dt_upsample2x_bwd_bn_bf16_rows(B, Hh // 2, Ww // 2, cx)
+                red = self._buf("bn_red_up", lib.dt_bn_stats_floats(P, cx), device=dev)
+                psc, psh = self._ss(pb, bnws)
+                fuse = _lib.BnBwdFuse(_p(y2p), _p(bnws[pb.bn_off:pb.bn_off + cx]),
+                                      _p(bnws[nb + pb.bn_off:nb + pb.bn_off + cx]), _p(psc), _p(psh))
+                _lib.check(lib.dt_upsample2x_bwd_bn_bf16(_p(dup), _p(g), C.byref(fuse), _p(red), B, Hh // 2, Ww // 2, cx,
+                                                         st), "dt_upsample2x_bwd_bn_bf16")
+                g_red = (red, P)
+            else:
+                _lib.check(lib.dt_upsample2x_bwd_bf16(_p(dup), _p(g), B, Hh // 2, Ww // 2, cx, st),
+                           "dt_upsample2x_bwd_bf16")
             del dup
             S[f"D{i}"] = None
         if self.grad_hook:
@@ -831,12 +846,14 @@ class UNetEngine:
 
         # ---- decoder (reverse)
         skip_grads = [None] * 5  # gradient of feats[0..4] = f1..f5
+        g_red = None             # BatchNorm-backward partial sums that already came with g (fused producers)
         for i in range(4, -1, -1):
             blk = sp.decoder[i]
             d = S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
             # conv2 + BN + ReLU (activation stored only for the last block)
-            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"], virtual_act=d["z2"] is None)
+            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"], virtual_act=d["z2"] is None,
+                               reduced=g_red)
             self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty_like(d["y1"])
             red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, d["y1"], bnws)
@@ -855,7 +872,23 @@ class UNetEngine:
                 self._dgrad(blk.conv1, params, dy1, B, Hh, Ww, dup)
             del dy1
             g = torch.empty_like(d["x"])
-            _lib.check(lib.dt_upsample2x_bwd(_p(dup), _p(g), 0, B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd")
+            g_red = None
+            if i >= 1 and d["x_virtual"]:
+                # g is the gradient of relu(bn(y2)) of decoder block i-1 (never stored): its BatchNorm-backward
+                # reduction rides along in the pass that writes g
+                pb = sp.decoder[i - 1].conv2
+                y2p = S[f"D{i - 1}"]["y2"]
+                P = lib.dt_upsample2x_bwd_bn_rows(B, Hh // 2, Ww // 2, cx)
+                red = self._buf("bn_red_up", lib.dt_bn_stats_floats(P, cx), device=dev)
+                psc, psh = self._ss(pb, bnws)
+                nbq = sp.n_bn_channels
+                fuse = _lib.BnBwdFuse(_p(y2p), _p(bnws[pb.bn_off: pb.bn_off + cx]),
+                                      _p(bnws[nbq + pb.bn_off: nbq + pb.bn_off + cx]), _p(psc), _p(psh))
+                _lib.check(lib.dt_upsample2x_bwd_bn(_p(dup), _p(g), C.byref(fuse), _p(red), B, Hh // 2, Ww // 2, cx, st),
+                           "dt_upsample2x_bwd_bn")
+                g_red = (red, P)
+            else:
+                _lib.check(lib.dt_upsample2x_bwd(_p(dup), _p(g), 0, B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd")
             del dup
             S[f"D{i}"] = None
         if self.grad_hook:

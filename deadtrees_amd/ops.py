@@ -334,6 +334,23 @@ def conv2d_bf16_bn_bwd(src0, w_packed, cout, y, mean, invstd, act_scale, act_shi
     return out, red[:2 * P * cout].view(2, P, cout)
 
 
+def upsample2x_bwd_bn(dup, y, mean, invstd, act_scale, act_shift):
+    """2x2-sum backward of a nearest x2 upsample + the BatchNorm-backward partial sums of the layer with raw output
+    `y` ([B,H,W,C], fp32 or bf16 like dup) -> (dx, red [2,P,C])"""
+    _gpu(dup, y, mean, invstd, act_scale, act_shift)
+    lib = _lib.load()
+    B, H2, W2, Cc = dup.shape
+    H, W = H2 // 2, W2 // 2
+    bf = dup.dtype == torch.bfloat16
+    P = (lib.dt_upsample2x_bwd_bn_bf16_rows if bf else lib.dt_upsample2x_bwd_bn_rows)(B, H, W, Cc)
+    red = torch.empty(lib.dt_bn_stats_floats(P, Cc), dtype=torch.float32, device=dup.device)
+    dx = torch.empty((B, H, W, Cc), dtype=dup.dtype, device=dup.device)
+    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift))
+    fn = lib.dt_upsample2x_bwd_bn_bf16 if bf else lib.dt_upsample2x_bwd_bn
+    _lib.check(fn(_p(dup.contiguous()), _p(dx), C.byref(fuse), _p(red), B, H, W, Cc, _st()), "dt_upsample2x_bwd_bn")
+    return dx, red[:2 * P * Cc].view(2, P, Cc)
+
+
 # ---- bf16 elementwise kernels (thin wrappers; the engine calls the C ABI directly with its own buffers)
 def bn_act_bf16(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
     """bf16 (or fp32) y [.., C] -> bf16 act(y*scale+shift + (res*rscale+rshift))"""

@@ -300,6 +300,17 @@ int dt_weight_images(const float* params, void* out, const int32_t* table, int n
 int dt_conv2d_bf16_bn_bwd(const dt_conv_desc* desc, const void* src0, const void* w_bf16, void* out, float* red,
                           const dt_bn_bwd_fuse* fuse, void* stream);
 
+/* Nearest x2 upsample backward (2x2 sums, like dt_upsample2x_bwd) with the BatchNorm-backward reduction of the layer
+ * whose (virtual) activation was upsampled fused in: dx[B,H,W,C] is that layer's output gradient, fuse->y its raw
+ * output; red[2][P][C], P = dt_upsample2x_bwd_bn_rows(...), holds dt_bn_stats_floats(P, C) floats -> dt_bn_bwd_apply.
+ * The _bf16 twins take bf16 tensors (fuse->y bf16) and follow dt_bn_bwd_reduce_bf16's arithmetic. */
+int dt_upsample2x_bwd_bn_rows(int B, int H, int W, int C);
+int dt_upsample2x_bwd_bn(const float* dup, float* dx, const dt_bn_bwd_fuse* fuse, float* red, int B, int H, int W, int C,
+                         void* stream);
+int dt_upsample2x_bwd_bn_bf16_rows(int B, int H, int W, int C);
+int dt_upsample2x_bwd_bn_bf16(const void* dup, void* dx, const dt_bn_bwd_fuse* fuse, float* red, int B, int H, int W,
+                              int C, void* stream);
+
 /* ------------------------------------------------------------------ optimiser (K22) */
 /* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
 int dt_sumsq_rows(int64_t n);

@@ -342,3 +342,36 @@ def test_conv_with_fused_bn_backward_reduction(B, H, W, Cin, Cout):
     scale = float(gm.abs().sum(dim=(0, 2, 3)).max()) + 1.0
     assert float((sums[0] - gm.sum(dim=(0, 2, 3))).abs().max()) <= 2e-5 * scale
     assert float((sums[1] - (gm * xh).sum(dim=(0, 2, 3))).abs().max()) <= 6e-5 * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 20, 64), (1, 33, 17, 16), (3, 64, 64, 32), (2, 5, 7, 256)])
+def test_upsample_backward_with_fused_bn_reduction(dtype, B, H, W, C):
+    """dt_upsample2x_bwd_bn(_bf16): dx bit-identical to dt_upsample2x_bwd(_bf16); partial sums = BatchNorm-backward
+    reduction of (dx, y) with the virtual-activation mask."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H + C)
+    dup = torch.randn((B, 2 * H, 2 * W, C), generator=g).to(dtype)
+    y = (torch.randn((B, H, W, C), generator=g) * 1.3 + 0.1).to(dtype)
+    mean = y.float().mean(dim=(0, 1, 2))
+    invstd = 1.0 / torch.sqrt(y.float().var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    sc, sh = gamma * invstd, beta - mean * gamma * invstd
+    dx, red = ops.upsample2x_bwd_bn(dup.to(DEV), y.to(DEV), mean.to(DEV), invstd.to(DEV), sc.to(DEV), sh.to(DEV))
+    if dtype == torch.float32:
+        plain = torch.empty((B, H, W, C), dtype=dtype, device=DEV)
+        from deadtrees_amd import _lib
+        _lib.check(_lib.load().dt_upsample2x_bwd(dup.to(DEV).data_ptr(), plain.data_ptr(), 0, B, H, W, C,
+                                                 torch.cuda.current_stream().cuda_stream), "dt_upsample2x_bwd")
+        act = y * sc + sh
+    else:
+        plain = ops.upsample2x_bwd_bf16(dup.to(DEV))
+        act = (y.float() * sc + sh).to(torch.bfloat16).float()
+    assert torch.equal(dx, plain)
+    d64 = dx.float().cpu().double()
+    gm = torch.where(act > 0, d64, torch.zeros_like(d64))
+    xh = (y.double() - mean.double()) * invstd.double()
+    sums = red.sum(dim=1).cpu().double()
+    scale = float(gm.abs().sum(dim=(0, 1, 2)).max()) + 1.0
+    assert float((sums[0] - gm.sum(dim=(0, 1, 2))).abs().max()) <= 3e-5 * scale
+    assert float((sums[1] - (gm * xh).sum(dim=(0, 1, 2))).abs().max()) <= 1e-4 * scale
