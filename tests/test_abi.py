@@ -44,3 +44,19 @@ def test_host_side_validation_without_gpu():
     assert lib.dt_conv2d_wgrad_workspace(ctypes.byref(ok)) > 0
     odd = _lib.ConvDesc(2, 64, 64, 64, 0, 0, 64, 64, 64, 5, 1, 2, 0, 0)
     assert lib.dt_conv2d_wgrad_workspace(ctypes.byref(odd)) == 0
+
+
+def test_public_header_is_plain_c99(tmp_path):
+    """include/deadtrees_hip.h is the drop-in boundary: it must compile as C (no C++ / torch types) with gcc."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "t.c"
+    src.write_text('#include "deadtrees_hip.h"\nint main(void) { dt_conv_desc d; dt_bn_bwd_fuse f; (void)d; (void)f; '
+                   'return (int)sizeof(d); }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o",
+                        str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
