@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
