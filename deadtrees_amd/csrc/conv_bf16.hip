@@ -52,8 +52,9 @@ struct BfGeom {
 // MT = MFMA row tiles (32 pixels) per wave: 2 -> 256-pixel workgroup tiles; 4 (with CK = 16) -> 512-pixel tiles.
 // The bf16 kernels are bound by global->LDS staging: a 512 x 64 tile stages 248 FLOP per byte
 // instead of 161 and needs 0.75 instead of 1 LDS fragment per MFMA; 16-channel chunks keep two workgroups per CU.
+// 3x3 stride-2 variants: the halo image alone is 88 KB -> one workgroup per CU, bounds say so.
 template <int KS, int STRIDE, int TW, int TN, int CK, int MT, bool TF>
-__global__ __launch_bounds__(256, 2) void conv_fwd_bf16_kernel(const ConvBfArgs a) {
+__global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_fwd_bf16_kernel(const ConvBfArgs a) {
   constexpr int TPX = 128 * MT;
   using G = BfGeom<KS, STRIDE, TW, TPX>;
   constexpr int BF_PITCH = CK + 8, SEG = CK / 8, ROWS_IT = 256 / SEG;
@@ -801,7 +802,7 @@ typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 // the 4 waves split the PIXEL rows of each tile instead and are summed through LDS once at the end, so no wave
 // multiplies zero padding.
 template <int KS, int STRIDE, int TW, bool TF, int BLK>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradBfArgs a) {
+__global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_wgrad_bf16_kernel(const WgradBfArgs a) {
   constexpr int TPX = 128, TH = TPX / TW;
   constexpr int LS = (KS == 1) ? 1 : STRIDE, GS = (KS == 1) ? STRIDE : 1;
   constexpr int HALO_H = (TH - 1) * LS + KS, HALO_W = (TW - 1) * LS + KS;
