@@ -384,6 +384,14 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_fw
 static int bf_validate(const dt_conv_desc* d) {
   DT_REQUIRE(d != nullptr, "conv_bf16: null descriptor");
   DT_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv_bf16: bad sizes");
+  if (d->ksize == 4) {
+    // the space-to-depth stem (dt_stem_s2d_bf16): 4x4 stride-1 window over 16 channels, 2 rows/cols of padding before
+    // and 1 after (pad = 2), same-size output
+    DT_REQUIRE(d->stride == 1 && d->pad == 2 && d->C0 == 16 && d->C1 == 0 && d->mode0 == 0 && (d->Cout % 64) == 0 &&
+                   d->cout_split == 0 && d->accumulate == 0 && d->Ho == d->Hin && d->Wo == d->Win && d->Wo > 16,
+               "conv_bf16: ksize 4 is the space-to-depth stem only (16 channels, pad 2, Cout %% 64 == 0)");
+    return DT_OK;
+  }
   DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && (d->stride == 2 || d->stride == 1)),
              "conv_bf16: ksize/stride (%d,%d) unsupported", d->ksize, d->stride);
   DT_REQUIRE((d->C0 & 7) == 0 && (d->C1 & 7) == 0 && (d->Cout & 7) == 0, "conv_bf16: channels must be multiples of 8");
@@ -429,6 +437,10 @@ static int bf_dispatch(const ConvBfArgs& a, int tw, int tn, int ck, int mt, hipS
 }
 
 static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_, int* ck_, int* mt_) {
+  if (d->ksize == 4) {   // space-to-depth stem: one variant
+    *tw_ = 32; *tn_ = 64; *ck_ = 16; *mt_ = 2;
+    return;
+  }
   const int tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
   int tn = d->Cout >= 64 ? 64 : 32;
   if (d->cout_split > 0 && (d->cout_split % 64) != 0) tn = 32;
@@ -508,6 +520,10 @@ static int conv2d_bf16_impl(const dt_conv_desc* d, const void* src0, const void*
   a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 128 * mt / tw); a.n_tiles = dt_cdiv(d->Cout, tn);
   a.P = d->B * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
+  if (d->ksize == 4) {
+    DT_REQUIRE(in_scale == nullptr && fuse == nullptr, "conv_bf16: the stem takes no input transform / fused reduction");
+    return bf_launch<4, 1, 32, 64, 16, 2>(a, st);
+  }
   if (d->ksize == 3 && d->stride == 1) return bf_dispatch<3, 1>(a, tw, tn, ck, mt, st);
   if (d->ksize == 3 && d->stride == 2) return bf_dispatch<3, 2>(a, tw, tn, ck, mt, st);
   if (d->ksize == 1 && d->stride == 1) return bf_dispatch<1, 1>(a, tw, tn, ck, mt, st);
@@ -559,6 +575,67 @@ extern "C" int dt_pack_dgrad_weights_bf16(const float* w_hwio, void* out, int ks
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(pack_dgrad_weights_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w_hwio,
                      (__bf16*)out, ksize * ksize, per_tap);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// ------------------------------------------------------------------ the 7x7 / stride-2 stem on the bf16 kernels
+// A 7x7 stride-2 window over C <= 4 channels is a 4x4 stride-1 window over the 2x2 space-to-depth image with
+// 4*4 = 16 channels: input row 2u + a (a in {0,1}) of window row kh = 2*ku + a - 1, ku = 0..3 (ku = 0, a = 0 falls
+// outside the 7 taps: zero weight).  dt_stem_s2d_bf16 builds that image ([B,H/2,W/2,16] bf16, channel (a*2+b)*4 + c),
+// dt_stem_pack_weights_bf16 the matching [16 taps][Cout][16] weights; dt_conv2d_bf16 with ksize = 4, pad = 2 then
+// computes the stem with v_mfma_f32_32x32x16_bf16 (K = 256, 147 of them real) instead of fp32 MFMA.
+__global__ __launch_bounds__(256) void stem_s2d_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ out, int B,
+                                                            int H, int W, int Cin) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const int64_t total = (int64_t)B * H2 * W2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % W2);
+    const int u = (int)((i / W2) % H2);
+    const int b = (int)(i / ((int64_t)W2 * H2));
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      const float* px = x + (((size_t)b * H + 2 * u + (ab >> 1)) * W + 2 * v + (ab & 1)) * Cin;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const __bf16 val = c < Cin ? (__bf16)px[c] : (__bf16)0.f;
+        if (ab < 2) lo[(ab & 1) * 4 + c] = val; else hi[(ab & 1) * 4 + c] = val;
+      }
+    }
+    reinterpret_cast<bf16x8*>(out)[2 * i] = lo;
+    reinterpret_cast<bf16x8*>(out)[2 * i + 1] = hi;
+  }
+}
+
+extern "C" int dt_stem_s2d_bf16(const float* x_nhwc, void* out, int B, int H, int W, int Cin, void* stream) {
+  DT_REQUIRE(x_nhwc && out && B > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0 && Cin >= 1 && Cin <= 4,
+             "stem_s2d_bf16: needs even H, W and 1..4 channels");
+  int64_t g = ((int64_t)B * (H / 2) * (W / 2) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(stem_s2d_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x_nhwc, (__bf16*)out, B,
+                     H, W, Cin);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+__global__ void stem_pack_weights_bf16_kernel(const float* __restrict__ w7, __bf16* __restrict__ out, int Cin, int Cout) {
+  // out[(ku*4 + kv)][co][(a*2+b)*4 + c] = w7[2ku+a-1][2kv+b-1][c][co]
+  const int total = 16 * Cout * 16;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int ch = i & 15, co = (i >> 4) % Cout, tap = i / (16 * Cout);
+    const int ku = tap >> 2, kv = tap & 3, a = ch >> 3, b = (ch >> 2) & 1, c = ch & 3;
+    const int kh = 2 * ku + a - 1, kw = 2 * kv + b - 1;
+    float v = 0.f;
+    if (kh >= 0 && kh < 7 && kw >= 0 && kw < 7 && c < Cin) v = w7[((size_t)(kh * 7 + kw) * Cin + c) * Cout + co];
+    out[i] = (__bf16)v;
+  }
+}
+
+extern "C" int dt_stem_pack_weights_bf16(const float* w_hwio, void* out, int Cin, int Cout, void* stream) {
+  DT_REQUIRE(w_hwio && out && Cin >= 1 && Cin <= 4 && Cout > 0, "stem_pack_weights_bf16: bad args");
+  hipLaunchKernelGGL(stem_pack_weights_bf16_kernel, dim3(dt_cdiv(16 * Cout * 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                     w_hwio, (__bf16*)out, Cin, Cout);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

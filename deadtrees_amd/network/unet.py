@@ -271,6 +271,29 @@ class UNetEngine:
         _lib.check(self.lib.dt_weight_images(_p(params), _p(out), _p(tab), n, tiles, mode, _stream()),
                    "dt_weight_images")
 
+    def _stem_bf16(self, x, params, y, stats, B, H, W, Cin):
+        """7x7/2 stem of the bf16 path into `y` (bf16) with optional BatchNorm partial statistics -> stat rows P.
+        Even tiles wider than 32 pixels run on the bf16 MFMA kernels through the 2x2 space-to-depth image
+        (dt_stem_s2d_bf16 + a 4x4 window: K = 256 bf16 instead of 147 fp32); anything else on the fp32 stem kernel."""
+        lib, stc, st = self.lib, self.spec.stem, _stream()
+        w7 = params[stc.w_off:stc.w_off + stc.w_size]
+        h, w_ = y.shape[1], y.shape[2]
+        if H % 2 == 0 and W % 2 == 0 and w_ > 16 and stc.cout % 64 == 0 and stc.k == 7 and stc.stride == 2:
+            s2d = torch.empty((B, h, w_, 16), dtype=torch.bfloat16, device=x.device)
+            _lib.check(lib.dt_stem_s2d_bf16(_p(x), _p(s2d), B, H, W, Cin, st), "dt_stem_s2d_bf16")
+            wp = self._buf("stem_w4", 16 * stc.cout * 16, dtype=torch.bfloat16, device=x.device)
+            _lib.check(lib.dt_stem_pack_weights_bf16(_p(w7), _p(wp), Cin, stc.cout, st), "dt_stem_pack_weights_bf16")
+            desc = self._desc(B, h, w_, 16, 0, 0, h, w_, stc.cout, 4, 1, 2)
+            P = lib.dt_conv2d_bf16_stat_rows(C.byref(desc))
+            sbuf = self._buf("bn_stats", lib.dt_bn_stats_floats(P, stc.cout), device=x.device) if stats else None
+            self._conv_bf16(desc, s2d, None, wp, y, None, sbuf, None, "dt_conv2d_bf16(stem)")
+            return P, sbuf
+        sdesc = self._desc(B, H, W, Cin, 0, 0, h, w_, stc.cout, stc.k, stc.stride, stc.pad)
+        P = lib.dt_conv2d_stat_rows(C.byref(sdesc))
+        sbuf = self._buf("bn_stats", lib.dt_bn_stats_floats(P, stc.cout), device=x.device) if stats else None
+        _lib.check(lib.dt_conv2d_out_bf16(C.byref(sdesc), _p(x), _p(w7), _p(y), _p(sbuf), st), "dt_conv2d_out_bf16")
+        return P, sbuf
+
     def _bf16_weights(self, params: torch.Tensor, dgrad: bool = False):
         """bf16 images of every conv weight except stem and head: [tap][Cout][Cin] for the forward convs, or the
         data-gradient image (HWIO with reversed taps).  Repacked when the flat parameter buffer changed: torch's
@@ -302,6 +325,8 @@ class UNetEngine:
             flops = 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout * desc.Ho * desc.Wo * desc.B
             if desc.mode0 == 2:
                 flops /= 4.0
+            if desc.ksize == 4:   # space-to-depth stem: the algorithmic work is the 7x7 x in_channels window
+                flops = 2.0 * 49 * self.spec.in_channels * desc.Cout * desc.Ho * desc.Wo * desc.B
             sdiv = 4 if desc.mode0 else 1
             nbytes = 2.0 * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
                                      desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
@@ -389,13 +414,11 @@ class UNetEngine:
 
         x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
         _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw.contiguous()), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
-        # stem: fp32 operands (K = 147), output stored as bf16
+        # stem: bf16 MFMA over the space-to-depth image (fp32-MFMA kernel for odd / tiny tiles), bf16 output
         stc = sp.stem
         h, w_ = (H + 2 * stc.pad - stc.k) // stc.stride + 1, (W + 2 * stc.pad - stc.k) // stc.stride + 1
-        sdesc = self._desc(B, H, W, Cin, 0, 0, h, w_, stc.cout, stc.k, stc.stride, stc.pad)
         y = torch.empty((B, h, w_, stc.cout), dtype=bf, device=dev)
-        _lib.check(lib.dt_conv2d_out_bf16(C.byref(sdesc), _p(x), _p(params[stc.w_off:stc.w_off + stc.w_size]), _p(y),
-                                          None, st), "dt_conv2d_out_bf16")
+        self._stem_bf16(x, params, y, False, B, H, W, Cin)
         f1 = bn_act(y, affine(stc))
         hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
         pool = torch.empty((B, hp, wp, 64), dtype=bf, device=dev)
@@ -483,15 +506,11 @@ class UNetEngine:
 
         x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
         _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw.contiguous()), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
-        # stem: fp32 operands (K = 147), bf16 output, fp32 statistics
+        # stem: bf16 MFMA over the space-to-depth image (fp32-MFMA kernel for odd / tiny tiles), fp32 statistics
         stc = sp.stem
         h, w_ = (H + 2 * stc.pad - stc.k) // stc.stride + 1, (W + 2 * stc.pad - stc.k) // stc.stride + 1
-        sdesc = self._desc(B, H, W, Cin, 0, 0, h, w_, stc.cout, stc.k, stc.stride, stc.pad)
-        Pst = lib.dt_conv2d_stat_rows(C.byref(sdesc))
-        sstats = self._buf("bn_stats", lib.dt_bn_stats_floats(Pst, stc.cout), device=dev)
         ystem = torch.empty((B, h, w_, stc.cout), dtype=bf, device=dev)
-        _lib.check(lib.dt_conv2d_out_bf16(C.byref(sdesc), _p(x), _p(params[stc.w_off:stc.w_off + stc.w_size]), _p(ystem),
-                                          _p(sstats), st), "dt_conv2d_out_bf16")
+        Pst, sstats = self._stem_bf16(x, params, ystem, True, B, H, W, Cin)
         ss = finalize(stc, sstats, Pst, B * h * w_)
         f1 = bn_act(ystem, ss)
         sv.d["stem"] = dict(x=x, y=ystem, z=f1, Hin=H, Win=W)

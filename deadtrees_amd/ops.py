@@ -351,6 +351,34 @@ def upsample2x_bwd_bn(dup, y, mean, invstd, act_scale, act_shift):
     return dx, red[:2 * P * Cc].view(2, P, Cc)
 
 
+def stem_conv_bf16(x_nhwc_f32, w_hwio_7x7, want_stats=False):
+    """the 7x7 / stride-2 / pad-3 stem on the bf16 MFMA kernels: fp32 NHWC image [B,H,W,Cin<=4] -> bf16
+    [B,H/2,W/2,Cout] (+ fp32 BatchNorm partial statistics), via the 2x2 space-to-depth image and a 4x4 window"""
+    _gpu(x_nhwc_f32, w_hwio_7x7)
+    lib = _lib.load()
+    B, H, W, Cin = x_nhwc_f32.shape
+    Cout = w_hwio_7x7.shape[-1]
+    st = _st()
+    s2d = torch.empty((B, H // 2, W // 2, 16), dtype=torch.bfloat16, device=x_nhwc_f32.device)
+    _lib.check(lib.dt_stem_s2d_bf16(_p(x_nhwc_f32.contiguous()), _p(s2d), B, H, W, Cin, st), "dt_stem_s2d_bf16")
+    wp = torch.empty(16 * Cout * 16, dtype=torch.bfloat16, device=x_nhwc_f32.device)
+    _lib.check(lib.dt_stem_pack_weights_bf16(_p(w_hwio_7x7.contiguous()), _p(wp), Cin, Cout, st),
+               "dt_stem_pack_weights_bf16")
+    d = _lib.ConvDesc(B, H // 2, W // 2, 16, 0, 0, H // 2, W // 2, Cout, 4, 1, 2, 0, 0)
+    out = torch.empty((B, H // 2, W // 2, Cout), dtype=torch.bfloat16, device=x_nhwc_f32.device)
+    stats = None
+    if want_stats:
+        P = lib.dt_conv2d_bf16_stat_rows(C.byref(d))
+        if P <= 0:
+            raise RuntimeError(lib.dt_last_error().decode())
+        stats = torch.empty(lib.dt_bn_stats_floats(P, Cout), dtype=torch.float32, device=out.device)
+    _lib.check(lib.dt_conv2d_bf16(C.byref(d), _p(s2d), None, _p(wp), _p(out), None, _p(stats), None, None, st),
+               "dt_conv2d_bf16(stem)")
+    if stats is not None:
+        stats = stats[:2 * P * Cout].view(2, P, Cout)
+    return out, stats
+
+
 # ---- bf16 elementwise kernels (thin wrappers; the engine calls the C ABI directly with its own buffers)
 def bn_act_bf16(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
     """bf16 (or fp32) y [.., C] -> bf16 act(y*scale+shift + (res*rscale+rshift))"""

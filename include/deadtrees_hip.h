@@ -294,6 +294,14 @@ int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C
 int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles, int mode,
                      void* stream);
 
+/* The 7x7 / stride-2 stem on the bf16 convolution kernels (smp encoder conv1, reached from network/segmodel.py:214):
+ * dt_stem_s2d_bf16 turns the fp32 NHWC image [B,H,W,Cin<=4] into its 2x2 space-to-depth form [B,H/2,W/2,16] bf16
+ * (channel (a*2+b)*4 + c, unused channels zero), dt_stem_pack_weights_bf16 the HWIO 7x7 weights into the matching
+ * [16 taps][Cout][16] image; dt_conv2d_bf16 with ksize = 4, stride 1, pad = 2 (C0 = 16, Ho = Hin, Wo = Win,
+ * Cout %% 64 == 0) is then exactly the 7x7/2 convolution on bf16-rounded operands. */
+int dt_stem_s2d_bf16(const float* x_nhwc, void* out_bf16, int B, int H, int W, int Cin, void* stream);
+int dt_stem_pack_weights_bf16(const float* w_hwio_7x7, void* out_bf16, int Cin, int Cout, void* stream);
+
 /* bf16 twin of dt_conv2d_bn_bwd: fuse->y points at the bf16 raw output of the BatchNorm layer (cast to const
  * float*); the sums use the rounded bf16 gradient and the mask of bf16(y*scale+shift), like dt_bn_bwd_reduce_bf16.
  * P = dt_conv2d_bf16_stat_rows(desc). */

@@ -302,3 +302,21 @@ def test_conv_bf16_with_fused_bn_backward_reduction(B, H, W, Cin, Cout):
     scale = float(gm.abs().sum(dim=(0, 2, 3)).max()) + 1.0
     assert float((sums[0] - gm.sum(dim=(0, 2, 3))).abs().max()) <= 3e-5 * scale
     assert float((sums[1] - (gm * xh).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 64, 96, 3), (1, 128, 128, 4), (3, 34, 70, 3), (2, 512, 512, 3)])
+def test_stem_on_bf16_kernels_via_space_to_depth(B, H, W, Cin):
+    """7x7 / stride 2 / pad 3 stem as a 4x4 window over the space-to-depth image: equals the fp64 convolution of the
+    bf16-rounded image and weights (one bf16 rounding of the result), statistics from the fp32 accumulators."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((64, Cin, 7, 7), generator=g) * (2.0 / (Cin * 49)) ** 0.5
+    ref = F.conv2d(x.to(BF).double(), w.to(BF).double(), stride=2, padding=3)
+    y, stats = ops.stem_conv_bf16(x.permute(0, 2, 3, 1).contiguous().to(DEV), w.permute(2, 3, 1, 0).contiguous().to(DEV),
+                                  want_stats=True)
+    assert tuple(y.shape) == (B, H // 2, W // 2, 64)
+    close_bf16(to_nchw(y), ref)
+    st = stats.sum(dim=1).cpu().double()
+    assert float((st[0] - ref.sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max())
+    assert float((st[1] - (ref * ref).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float((ref * ref).sum(dim=(0, 2, 3)).max())
