@@ -83,6 +83,7 @@ SIGNATURES = {
     "dt_upsample2x_bwd_bn_bf16": (C.c_int, [c_f, c_f, C.POINTER(BnBwdFuse), c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_stem_s2d_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_stem_pack_weights_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f]),
+    "dt_stem_unpack_wgrad": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_weight_images": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_ensemble_vote": (C.c_int, [c_f, C.c_int, I64, C.c_int, c_f, c_f, c_f, c_f]),
     "dt_signed_distmap_workspace": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),

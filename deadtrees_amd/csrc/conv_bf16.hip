@@ -640,6 +640,26 @@ extern "C" int dt_stem_pack_weights_bf16(const float* w_hwio, void* out, int Cin
   return DT_OK;
 }
 
+// weight gradient of the space-to-depth stem back to the 7x7 HWIO layout:
+// dw7[kh][kw][c][co] = dw4[(ku*4 + kv)][(a*2+b)*4 + c][co] with kh = 2ku + a - 1, kw = 2kv + b - 1
+__global__ void stem_unpack_wgrad_kernel(const float* __restrict__ dw4, float* __restrict__ dw7, int Cin, int Cout) {
+  const int total = 49 * Cin * Cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % Cout, c = (i / Cout) % Cin, tap = i / (Cout * Cin);
+    const int kh = tap / 7, kw = tap % 7;
+    const int ku = (kh + 1) >> 1, a = (kh + 1) & 1, kv = (kw + 1) >> 1, b = (kw + 1) & 1;
+    dw7[i] = dw4[((size_t)(ku * 4 + kv) * 16 + (a * 2 + b) * 4 + c) * Cout + co];
+  }
+}
+
+extern "C" int dt_stem_unpack_wgrad(const float* dw4, float* dw_hwio_7x7, int Cin, int Cout, void* stream) {
+  DT_REQUIRE(dw4 && dw_hwio_7x7 && Cin >= 1 && Cin <= 4 && Cout > 0, "stem_unpack_wgrad: bad args");
+  hipLaunchKernelGGL(stem_unpack_wgrad_kernel, dim3(dt_cdiv(49 * Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream,
+                     dw4, dw_hwio_7x7, Cin, Cout);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ all weight images of a network in ONE launch
 // The per-layer pack / flip kernels above are 4-5 us each and there are ~45 layers: 90-135 launches per step.
 // Table-driven variant over the flat parameter buffer: row l = (w_off, taps, Cin, Cout, first_tile); a workgroup
@@ -884,13 +904,18 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_wg
   constexpr int LS = (KS == 1) ? 1 : STRIDE, GS = (KS == 1) ? STRIDE : 1;
   constexpr int HALO_H = (TH - 1) * LS + KS, HALO_W = (TW - 1) * LS + KS;
   constexpr int TAPS = KS * KS;
+  // KS = 4 (the space-to-depth stem): 16 taps would need 256 accumulator registers, so two workgroups share a
+  // (ci, co) block and take 8 taps (two window rows) each
+  constexpr int TG = (KS == 4) ? 2 : 1, NTAP = TAPS / TG;
   constexpr int X_ROWS = HALO_H * HALO_W;
   __shared__ __attribute__((aligned(16))) __bf16 lds[(X_ROWS + TPX) * WB_PITCH];
   __shared__ __attribute__((aligned(16))) float lds_tf[TF ? 128 : 4];
   __bf16* lx = lds;
   __bf16* ly = lds + X_ROWS * WB_PITCH;
   const int wgid = (int)xcd_remap(blockIdx.x, gridDim.x);
-  const int blk = wgid % (a.ci_blocks * a.co_blocks), ks = wgid / (a.ci_blocks * a.co_blocks);
+  const int nblk = a.ci_blocks * a.co_blocks;
+  const int blk = wgid % nblk, tg = (wgid / nblk) % TG, ks = wgid / (nblk * TG);
+  const int kh0 = tg * (NTAP / KS);    // first window row of this workgroup's tap group
   const int ci0 = (blk / a.co_blocks) * BLK, co0 = (blk % a.co_blocks) * BLK;
   const int Cin = a.C0 + a.C1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -905,9 +930,9 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_wg
       lds_tf[64 + tid] = a.in_shift[ci0 + tid];
     }
   }
-  f32x16 acc[TAPS];
+  f32x16 acc[NTAP];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
@@ -1000,8 +1025,8 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_wg
           }
         }
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          const int kh = t / KS, kw = t % KS;
+        for (int t = 0; t < NTAP; ++t) {
+          const int kh = kh0 + t / KS, kw = t % KS;
           const int e = xlane + ((row * LS + kh) * HALO_W + 16 * xs * LS + kw) * WB_PITCH;
           const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lx + e));
           const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lx + e + 4 * LS * WB_PITCH));
@@ -1018,20 +1043,20 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_wg
   }
   if constexpr (BLK == 32) {
     // sum the four pixel shares in wave 0 (fixed order 1, 2, 3 -> deterministic)
-    float* red = reinterpret_cast<float*>(lds);   // [TAPS][16][64] fp32 <= 36 KB, inside the operand images
-    static_assert((size_t)TAPS * 16 * 64 * sizeof(float) <= sizeof(lds), "reduction image must fit the tiles");
+    float* red = reinterpret_cast<float*>(lds);   // [NTAP][16][64] fp32 <= 36 KB, inside the operand images
+    static_assert((size_t)NTAP * 16 * 64 * sizeof(float) <= sizeof(lds), "reduction image must fit the tiles");
     for (int w = 1; w < 4; ++w) {
       __syncthreads();
       if (wave == w) {
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int t = 0; t < NTAP; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) red[(t * 16 + i) * 64 + lane] = acc[t][i];
       }
       __syncthreads();
       if (wave == 0) {
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int t = 0; t < NTAP; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[t][i] += red[(t * 16 + i) * 64 + lane];
       }
@@ -1043,11 +1068,11 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_wg
   const int co = co0 + wco * 32 + r;
   if (co < a.Cout) {
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ci = ci0 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (ci < Cin) a.ws[(((size_t)part * TAPS + t) * Cin + ci) * a.Cout + co] = acc[t][i];
+        if (ci < Cin) a.ws[(((size_t)part * TAPS + tg * NTAP + t) * Cin + ci) * a.Cout + co] = acc[t][i];
       }
   }
 }
@@ -1055,12 +1080,13 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_wg
 static int wb_cfg(const dt_conv_desc* d, int* tw, int* ksplit, int* T, int* cib, int* cob) {
   const int Cin = d->C0 + d->C1;
   *tw = d->Wo > 16 ? 32 : 16;
-  const int blk = (Cin <= 32 && d->Cout <= 32 && d->ksize == 3 && d->stride == 1) ? 32 : 64;
+  const bool stem = d->ksize == 4;
+  const int blk = ((Cin <= 32 && d->Cout <= 32 && d->ksize == 3 && d->stride == 1) || stem) ? 32 : 64;
   *cib = dt_cdiv(Cin, blk);
   *cob = dt_cdiv(d->Cout, blk);
   const int th = 128 / *tw;
   *T = d->B * dt_cdiv(d->Ho, th) * dt_cdiv(d->Wo, *tw);
-  int ks = 512 / (*cib * *cob);
+  int ks = 512 / (*cib * *cob * (stem ? 2 : 1));
   if (ks < 1) ks = 1;
   if (ks > *T) ks = *T;
   *ksplit = ks;
@@ -1069,6 +1095,12 @@ static int wb_cfg(const dt_conv_desc* d, int* tw, int* ksplit, int* T, int* cib,
 
 static int wb_validate(const dt_conv_desc* d) {
   DT_REQUIRE(d != nullptr, "wgrad_bf16: null descriptor");
+  if (d->ksize == 4) {   // the space-to-depth stem (see dt_stem_s2d_bf16)
+    DT_REQUIRE(d->stride == 1 && d->pad == 2 && d->C0 == 16 && d->C1 == 0 && d->mode0 == 0 && (d->Cout % 32) == 0 &&
+                   d->Ho == d->Hin && d->Wo == d->Win && d->Wo > 16,
+               "wgrad_bf16: ksize 4 is the space-to-depth stem only");
+    return DT_OK;
+  }
   DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && d->stride == 2),
              "wgrad_bf16: ksize/stride (%d,%d) unsupported", d->ksize, d->stride);
   DT_REQUIRE((d->C0 & 7) == 0 && (d->C1 & 7) == 0 && (d->Cout & 7) == 0, "wgrad_bf16: channels must be multiples of 8");
@@ -1137,8 +1169,13 @@ extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, con
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.pad = d->pad;
   a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 128 / tw);
   hipStream_t st = (hipStream_t)stream;
-  const int grid = a.ci_blocks * a.co_blocks * a.ksplit;
-  if (d->ksize == 3 && d->stride == 1) rc = tw == 32 ? wb_launch<3, 1, 32>(a, grid, st) : wb_launch<3, 1, 16>(a, grid, st);
+  const int grid = a.ci_blocks * a.co_blocks * a.ksplit * (d->ksize == 4 ? 2 : 1);
+  if (d->ksize == 4) {
+    DT_REQUIRE(in_scale == nullptr, "wgrad_bf16: the stem takes no input transform");
+    hipLaunchKernelGGL((conv_wgrad_bf16_kernel<4, 1, 32, false, 32>), dim3(grid), dim3(256), 0, st, a);
+    DT_LAUNCH_CHECK();
+    rc = DT_OK;
+  } else if (d->ksize == 3 && d->stride == 1) rc = tw == 32 ? wb_launch<3, 1, 32>(a, grid, st) : wb_launch<3, 1, 16>(a, grid, st);
   else if (d->ksize == 3) rc = tw == 32 ? wb_launch<3, 2, 32>(a, grid, st) : wb_launch<3, 2, 16>(a, grid, st);
   else rc = tw == 32 ? wb_launch<1, 2, 32>(a, grid, st) : wb_launch<1, 2, 16>(a, grid, st);
   if (rc != DT_OK) return rc;

@@ -287,11 +287,13 @@ class UNetEngine:
             P = lib.dt_conv2d_bf16_stat_rows(C.byref(desc))
             sbuf = self._buf("bn_stats", lib.dt_bn_stats_floats(P, stc.cout), device=x.device) if stats else None
             self._conv_bf16(desc, s2d, None, wp, y, None, sbuf, None, "dt_conv2d_bf16(stem)")
+            self._stem_s2d = s2d if stats else None     # training: the weight gradient reuses the image
             return P, sbuf
         sdesc = self._desc(B, H, W, Cin, 0, 0, h, w_, stc.cout, stc.k, stc.stride, stc.pad)
         P = lib.dt_conv2d_stat_rows(C.byref(sdesc))
         sbuf = self._buf("bn_stats", lib.dt_bn_stats_floats(P, stc.cout), device=x.device) if stats else None
         _lib.check(lib.dt_conv2d_out_bf16(C.byref(sdesc), _p(x), _p(w7), _p(y), _p(sbuf), st), "dt_conv2d_out_bf16")
+        self._stem_s2d = None
         return P, sbuf
 
     def _bf16_weights(self, params: torch.Tensor, dgrad: bool = False):
@@ -513,7 +515,8 @@ class UNetEngine:
         Pst, sstats = self._stem_bf16(x, params, ystem, True, B, H, W, Cin)
         ss = finalize(stc, sstats, Pst, B * h * w_)
         f1 = bn_act(ystem, ss)
-        sv.d["stem"] = dict(x=x, y=ystem, z=f1, Hin=H, Win=W)
+        sv.d["stem"] = dict(x=x, y=ystem, z=f1, Hin=H, Win=W, s2d=self._stem_s2d)
+        self._stem_s2d = None
         hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
         pool = torch.empty((B, hp, wp, 64), dtype=bf, device=dev)
         amax = torch.empty((B, hp, wp, 64), dtype=torch.uint8, device=dev)
@@ -733,13 +736,27 @@ class UNetEngine:
                    "dt_maxpool3x3s2_bwd_bf16")
         dy = bn_bwd(sp.stem, gf1, stem["z"], stem["y"])
         stc = sp.stem
-        sdesc = self._desc(B, stem["Hin"], stem["Win"], stem["x"].shape[-1], 0, 0, dy.shape[1], dy.shape[2], stc.cout,
-                           stc.k, stc.stride, stc.pad)
-        nbytes = lib.dt_conv2d_wgrad_workspace(C.byref(sdesc))
-        ws = self._buf("wgrad_ws", nbytes // 4, device=dev)
-        _lib.check(lib.dt_conv2d_wgrad_stem_dy_bf16(C.byref(sdesc), _p(stem["x"]), _p(dy),
-                                                    _p(grads[stc.w_off:stc.w_off + stc.w_size]), _p(ws),
-                                                    ws.numel() * 4, st), "dt_conv2d_wgrad_stem_dy_bf16")
+        if stem.get("s2d") is not None:
+            # space-to-depth form on the bf16 MFMA kernels: dW over 16 taps x 16 channels, gathered back to 7x7
+            cin = stem["x"].shape[-1]
+            d4 = self._desc(B, dy.shape[1], dy.shape[2], 16, 0, 0, dy.shape[1], dy.shape[2], stc.cout, 4, 1, 2)
+            nbytes = lib.dt_conv2d_wgrad_bf16_workspace(C.byref(d4))
+            if nbytes == 0:
+                raise RuntimeError(lib.dt_last_error().decode())
+            ws = self._buf("wgrad_ws", nbytes // 4, device=dev)
+            dw4 = self._buf("stem_dw4", 16 * 16 * stc.cout, device=dev)
+            _lib.check(lib.dt_conv2d_wgrad_bf16(C.byref(d4), _p(stem["s2d"]), None, _p(dy), _p(dw4), _p(ws),
+                                                ws.numel() * 4, None, None, st), "dt_conv2d_wgrad_bf16(stem)")
+            _lib.check(lib.dt_stem_unpack_wgrad(_p(dw4), _p(grads[stc.w_off:stc.w_off + stc.w_size]), cin, stc.cout, st),
+                       "dt_stem_unpack_wgrad")
+        else:
+            sdesc = self._desc(B, stem["Hin"], stem["Win"], stem["x"].shape[-1], 0, 0, dy.shape[1], dy.shape[2], stc.cout,
+                               stc.k, stc.stride, stc.pad)
+            nbytes = lib.dt_conv2d_wgrad_workspace(C.byref(sdesc))
+            ws = self._buf("wgrad_ws", nbytes // 4, device=dev)
+            _lib.check(lib.dt_conv2d_wgrad_stem_dy_bf16(C.byref(sdesc), _p(stem["x"]), _p(dy),
+                                                        _p(grads[stc.w_off:stc.w_off + stc.w_size]), _p(ws),
+                                                        ws.numel() * 4, st), "dt_conv2d_wgrad_stem_dy_bf16")
         self._join_side()
         if self.grad_hook:
             self.grad_hook(*sp.buckets[4])

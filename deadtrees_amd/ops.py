@@ -379,6 +379,29 @@ def stem_conv_bf16(x_nhwc_f32, w_hwio_7x7, want_stats=False):
     return out, stats
 
 
+def stem_wgrad_bf16(x_nhwc_f32, dy_bf16):
+    """weight gradient of the 7x7 / stride-2 stem on the bf16 MFMA kernels (space-to-depth form) -> fp32 HWIO
+    [7,7,Cin,Cout]; dy bf16 [B,H/2,W/2,Cout]"""
+    _gpu(x_nhwc_f32, dy_bf16)
+    lib = _lib.load()
+    B, H, W, Cin = x_nhwc_f32.shape
+    Cout = dy_bf16.shape[-1]
+    st = _st()
+    s2d = torch.empty((B, H // 2, W // 2, 16), dtype=torch.bfloat16, device=x_nhwc_f32.device)
+    _lib.check(lib.dt_stem_s2d_bf16(_p(x_nhwc_f32.contiguous()), _p(s2d), B, H, W, Cin, st), "dt_stem_s2d_bf16")
+    d = _lib.ConvDesc(B, H // 2, W // 2, 16, 0, 0, H // 2, W // 2, Cout, 4, 1, 2, 0, 0)
+    nbytes = lib.dt_conv2d_wgrad_bf16_workspace(C.byref(d))
+    if nbytes == 0:
+        raise RuntimeError(lib.dt_last_error().decode())
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=s2d.device)
+    dw4 = torch.empty(16 * 16 * Cout, dtype=torch.float32, device=s2d.device)
+    _lib.check(lib.dt_conv2d_wgrad_bf16(C.byref(d), _p(s2d), None, _p(dy_bf16.contiguous()), _p(dw4), _p(ws), nbytes,
+                                        None, None, st), "dt_conv2d_wgrad_bf16(stem)")
+    dw7 = torch.empty((7, 7, Cin, Cout), dtype=torch.float32, device=s2d.device)
+    _lib.check(lib.dt_stem_unpack_wgrad(_p(dw4), _p(dw7), Cin, Cout, st), "dt_stem_unpack_wgrad")
+    return dw7
+
+
 # ---- bf16 elementwise kernels (thin wrappers; the engine calls the C ABI directly with its own buffers)
 def bn_act_bf16(y, scale, shift, res=None, rscale=None, rshift=None, relu=True):
     """bf16 (or fp32) y [.., C] -> bf16 act(y*scale+shift + (res*rscale+rshift))"""

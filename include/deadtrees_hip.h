@@ -301,6 +301,9 @@ int dt_weight_images(const float* params, void* out, const int32_t* table, int n
  * Cout %% 64 == 0) is then exactly the 7x7/2 convolution on bf16-rounded operands. */
 int dt_stem_s2d_bf16(const float* x_nhwc, void* out_bf16, int B, int H, int W, int Cin, void* stream);
 int dt_stem_pack_weights_bf16(const float* w_hwio_7x7, void* out_bf16, int Cin, int Cout, void* stream);
+/* weight gradient of the stem in that form: dt_conv2d_wgrad_bf16 with ksize = 4 (C0 = 16, pad 2) gives
+ * dw4 fp32 [16 taps][16][Cout]; dt_stem_unpack_wgrad gathers it into the HWIO 7x7 gradient [7][7][Cin][Cout]. */
+int dt_stem_unpack_wgrad(const float* dw4, float* dw_hwio_7x7, int Cin, int Cout, void* stream);
 
 /* bf16 twin of dt_conv2d_bn_bwd: fuse->y points at the bf16 raw output of the BatchNorm layer (cast to const
  * float*); the sums use the rounded bf16 gradient and the mask of bf16(y*scale+shift), like dt_bn_bwd_reduce_bf16.

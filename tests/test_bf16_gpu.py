@@ -320,3 +320,19 @@ def test_stem_on_bf16_kernels_via_space_to_depth(B, H, W, Cin):
     st = stats.sum(dim=1).cpu().double()
     assert float((st[0] - ref.sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max())
     assert float((st[1] - (ref * ref).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * float((ref * ref).sum(dim=(0, 2, 3)).max())
+
+
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 64, 96, 3), (1, 128, 128, 4), (3, 34, 70, 3)])
+def test_stem_weight_gradient_on_bf16_kernels(B, H, W, Cin):
+    """stem dW through the space-to-depth form (16 taps split over two workgroups, unpacked to 7x7) against fp64
+    autograd on the bf16-rounded image and gradient"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H + Cin + 1)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    wt = (torch.randn((64, Cin, 7, 7), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(x.to(BF).double(), wt, stride=2, padding=3)
+    dy = torch.randn(y.shape, generator=g).to(BF)
+    y.backward(dy.double())
+    dw = ops.stem_wgrad_bf16(x.permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    got = dw.cpu().permute(3, 2, 0, 1).double()
+    assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 3e-5
