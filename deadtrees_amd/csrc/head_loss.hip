@@ -42,12 +42,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const void* __restrict__ 
   constexpr int C = HEAD_CIN;
   constexpr int HH = HEAD_TH + 2, HW_ = HEAD_TW + 2;
   __shared__ float tile[HH * HW_][C + 1];  // +1: odd pitch -> conflict-free per-pixel reads
-  __shared__ float wl[K * 9 * C];
+  // the K*9*16 weights are the same for every lane and their indices are compile-time constants after unrolling:
+  // read straight from `w` they become scalar loads (SGPR operands of the FMAs) instead of one LDS read per FMA
   const int tiles_x = (W + HEAD_TW - 1) / HEAD_TW, tiles_y = (H + HEAD_TH - 1) / HEAD_TH;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
   const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
   const int t = threadIdx.x;
-  for (int i = t; i < K * 9 * C; i += 256) wl[i] = w[i];
   for (int i = t; i < HH * HW_ * (C / 4); i += 256) {
     const int q = i % (C / 4), pix = i / (C / 4);
     const int hy = pix / HW_, hx = pix % HW_;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const void* __restrict__ 
       for (int c = 0; c < C; ++c) {
         const float xv = tp[c];
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] = fmaf(xv, wl[(k * 9 + kh * 3 + kw) * C + c], acc[k]);
+        for (int k = 0; k < K; ++k) acc[k] = fmaf(xv, w[(k * 9 + kh * 3 + kw) * C + c], acc[k]);
       }
     }
   if (oy < H && ox < W) {
@@ -137,12 +137,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ 
   constexpr int NW = K * 9 * C + K;
   __shared__ float xt[HH * HW_][C + 1];
   __shared__ float dlt[K][HH * HW_];
-  __shared__ float wl[K * 9 * C];
   const int tiles_x = (W + HEAD_TW - 1) / HEAD_TW, tiles_y = (H + HEAD_TH - 1) / HEAD_TH;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
   const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
   const int t = threadIdx.x;
-  for (int i = t; i < K * 9 * C; i += 256) wl[i] = w[i];
   for (int i = t; i < HH * HW_ * (C / 4); i += 256) {
     const int q = i % (C / 4), pix = i / (C / 4);
     const int hy = pix / HW_, hx = pix % HW_;
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ 
         for (int k = 0; k < K; ++k) {
           const float g = dlt[k][hp];
 #pragma unroll
-          for (int c = 0; c < C; ++c) a[c] = fmaf(g, wl[(k * 9 + kh * 3 + kw) * C + c], a[c]);
+          for (int c = 0; c < C; ++c) a[c] = fmaf(g, w[(k * 9 + kh * 3 + kw) * C + c], a[c]);   // scalar loads
         }
       }
     if (valid) {
