@@ -31,7 +31,7 @@ _P = C.POINTER(ConvDesc)
 
 
 class BnBwdFuse(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("y", "mean", "invstd", "act_scale", "act_shift")]
+    _fields_ = [(n, C.c_void_p) for n in ("y", "mean", "invstd", "act_scale", "act_shift", "act")]
 
 # name -> (restype, argtypes).  Must list every symbol of include/deadtrees_hip.h
 # (tests/test_abi.py cross-checks this table against the header).

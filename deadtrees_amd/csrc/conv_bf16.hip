@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_fw
   const bool join = a.accumulate && !second;
   constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS;
   const int seg = tid % SEGS, prow = tid / SEGS;
-  const bool bnb = a.bnb.y != nullptr && !join;   // uniform
+  const bool bnb = a.bnb.y != nullptr;   // uniform; join (accumulate) <=> mask from the stored activation a.bnb.act
   float q1[8], q2[8], b_mu[8], b_is[8], b_sc[8], b_sh[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) q1[k] = q2[k] = b_mu[k] = b_is[k] = b_sc[k] = b_sh[k] = 0.f;
@@ -244,8 +244,10 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_fw
     };
     ld8(a.bnb.mean, b_mu);
     ld8(a.bnb.invstd, b_is);
-    ld8(a.bnb.act_scale, b_sc);
-    ld8(a.bnb.act_shift, b_sh);
+    if (a.bnb.act == nullptr) {
+      ld8(a.bnb.act_scale, b_sc);
+      ld8(a.bnb.act_shift, b_sh);
+    }
   }
   // the tile is written out in slices of 256 pixels (MT / 2 of them) through the same staging image
 #pragma unroll
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_fw
             const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg;
             const f32x4 raw = *reinterpret_cast<const f32x4*>(lds + pl * OUT_PITCH + 8 * seg);
             *reinterpret_cast<f32x4*>(outp + o) = raw;
-            if (bnb) {
+            if (bnb) {   // (plain store: virtual activation, host check)
               // BatchNorm-backward partial sums from the ROUNDED gradient and the layer's raw output y, with the ReLU
               // mask the consumers saw (sign of bf16(y*sc+sh)) — the arithmetic of bn_bwd_reduce_bf16_kernel
               const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + o);
@@ -333,7 +335,20 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 2) ? 1 : 2) void conv_fw
               o[k] = (__bf16)(lo[k] + (float)o[k]);
               o[4 + k] = (__bf16)(hi[k] + (float)o[4 + k]);
             }
-            *reinterpret_cast<bf16x8*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg) = o;
+            const size_t oo = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * seg;
+            *reinterpret_cast<bf16x8*>(outp + oo) = o;
+            if (bnb) {   // sums over the joined (rounded) gradient, mask from the stored activation
+              const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + oo);
+              const f32x4 zraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.act) + oo);
+              const bf16x8 yv = *reinterpret_cast<const bf16x8*>(&yraw), zv = *reinterpret_cast<const bf16x8*>(&zraw);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float yk = (float)yv[k];
+                const float g = (float)zv[k] > 0.f ? (float)o[k] : 0.f;
+                q1[k] += g;
+                q2[k] += g * ((yk - b_mu[k]) * b_is[k]);
+              }
+            }
           }
         }
       }
@@ -489,10 +504,13 @@ extern "C" int dt_conv2d_bf16(const dt_conv_desc* d, const void* src0, const voi
 
 extern "C" int dt_conv2d_bf16_bn_bwd(const dt_conv_desc* d, const void* src0, const void* w_bf16, void* out, float* red,
                                      const dt_bn_bwd_fuse* fuse, void* stream) {
-  DT_REQUIRE(d && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale && fuse->act_shift,
-             "conv_bf16_bn_bwd: null pointer");
-  DT_REQUIRE(d->ksize == 3 && d->stride == 1 && d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0 && d->accumulate == 0,
+  DT_REQUIRE(d && fuse && red && fuse->y && fuse->mean && fuse->invstd, "conv_bf16_bn_bwd: null pointer");
+  DT_REQUIRE(fuse->act != nullptr || (fuse->act_scale && fuse->act_shift),
+             "conv_bf16_bn_bwd: give the stored activation or the scale/shift of a virtual one");
+  DT_REQUIRE(d->ksize == 3 && d->stride == 1 && d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0,
              "conv_bf16_bn_bwd: plain 3x3 stride-1 data gradients only");
+  DT_REQUIRE((d->accumulate != 0) == (fuse->act != nullptr),
+             "conv_bf16_bn_bwd: gradient joins (accumulate) go with a stored activation, plain stores with a virtual one");
   DT_REQUIRE((((uintptr_t)fuse->mean | (uintptr_t)fuse->invstd | (uintptr_t)fuse->act_scale |
                (uintptr_t)fuse->act_shift) & 15) == 0, "conv_bf16_bn_bwd: per-channel arrays must be 16-byte aligned");
   return conv2d_bf16_impl(d, src0, nullptr, w_bf16, out, nullptr, red, nullptr, nullptr, stream, fuse);
@@ -511,7 +529,7 @@ static int conv2d_bf16_impl(const dt_conv_desc* d, const void* src0, const void*
   int tw, tn, ck, mt;
   bf_cfg(d, &tw, &tn, &ck, &mt);
   ConvBfArgs a;
-  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.out1 = (__bf16*)out1; a.stats = stats; a.cout_split = d->cout_split; a.accumulate = d->accumulate;
   a.src0 = (const __bf16*)src0; a.src1 = (const __bf16*)src1; a.w = (const __bf16*)w_bf16;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out = (__bf16*)out;

@@ -467,8 +467,10 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
     if (bnb && nok) {
       b_mu = a.bnb.mean[n];
       b_is = a.bnb.invstd[n];
-      b_sc = a.bnb.act_scale[n];
-      b_sh = a.bnb.act_shift[n];
+      if (a.bnb.act == nullptr) {
+        b_sc = a.bnb.act_scale[n];
+        b_sh = a.bnb.act_shift[n];
+      }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -487,9 +489,28 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
         float prev[16];   // all 16 loads in flight before the first add (gradient accumulation joins)
 #pragma unroll
         for (int i = 0; i < 16; ++i) prev[i] = ok[i] ? outp[off[i]] : 0.f;
+        if (bnb) {
+          // join + BatchNorm-backward sums of the block-output layer: mask from its stored activation
+          float yv[16], zv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (ok[i]) outp[off[i]] = acc[mt][j][i] + prev[i];
+          for (int i = 0; i < 16; ++i) {
+            yv[i] = ok[i] ? a.bnb.y[off[i]] : 0.f;
+            zv[i] = ok[i] ? a.bnb.act[off[i]] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (ok[i]) {
+              const float v = acc[mt][j][i] + prev[i];
+              const float g = zv[i] > 0.f ? v : 0.f;
+              s1[j] += g;
+              s2[j] += g * ((yv[i] - b_mu) * b_is);
+              outp[off[i]] = v;
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (ok[i]) outp[off[i]] = acc[mt][j][i] + prev[i];
+        }
       } else if (bnb) {
         // BatchNorm-backward partial sums of the layer this gradient belongs to (its raw output y at the same
         // positions; 128-byte rows like the stores): g = v * [relu mask], sum g and sum g * xhat
@@ -500,7 +521,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
         for (int i = 0; i < 16; ++i)
           if (ok[i]) {
             const float v = acc[mt][j][i];
-            const float g = (yv[i] * b_sc + b_sh) > 0.f ? v : 0.f;
+            const float g = (yv[i] * b_sc + b_sh) > 0.f ? v : 0.f;   // virtual activation (act == nullptr: host check)
             s1[j] += g;
             s2[j] += g * ((yv[i] - b_mu) * b_is);
             outp[off[i]] = v;
@@ -632,10 +653,14 @@ extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* 
 
 extern "C" int dt_conv2d_bn_bwd(const dt_conv_desc* d, const float* src0, const float* w, float* out0, float* red,
                                 const dt_bn_bwd_fuse* fuse, void* stream) {
-  DT_REQUIRE(d && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale && fuse->act_shift,
-             "conv_bn_bwd: null pointer");
-  DT_REQUIRE(d->ksize == 3 && d->stride == 1 && d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0 && d->accumulate == 0,
+  DT_REQUIRE(d && fuse && red && fuse->y && fuse->mean && fuse->invstd, "conv_bn_bwd: null pointer");
+  DT_REQUIRE(fuse->act != nullptr || (fuse->act_scale && fuse->act_shift),
+             "conv_bn_bwd: give the stored activation or the scale/shift of a virtual one");
+  DT_REQUIRE(d->ksize == 3 && d->stride == 1 && d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0,
              "conv_bn_bwd: plain 3x3 stride-1 data gradients only");
+  DT_REQUIRE((d->accumulate != 0) == (fuse->act != nullptr),
+             "conv_bn_bwd: gradient joins (accumulate) go with a stored activation, plain stores with a virtual one");
+  DT_REQUIRE(!(d->accumulate && dt_conv2d_n16_supported(d)), "conv_bn_bwd: no join on the 16-wide kernels");
   return conv2d_impl(d, src0, nullptr, w, out0, nullptr, red, nullptr, nullptr, nullptr, stream, fuse);
 }
 
@@ -654,7 +679,7 @@ static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* sr
     return dt_conv2d_n16_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream, fuse);
   ConvCfg c = pick_cfg(d);
   ConvArgs a;
-  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.src0 = src0; a.src1 = src1; a.w = w; a.out0 = out0; a.out1 = out1; a.stats = stats;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out0_bf16 = (__bf16*)out_bf16;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;

@@ -198,7 +198,7 @@ int dt_conv2d_n16_rows(const dt_conv_desc* d) { return d->B * dt_cdiv(d->Ho, N16
 int dt_conv2d_n16_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
                          const float* in_scale, const float* in_shift, hipStream_t st, const dt_bn_bwd_fuse* fuse) {
   NarrowArgs a;
-  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.src0 = src0; a.w = w; a.out = out; a.stats = stats; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->C0; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;

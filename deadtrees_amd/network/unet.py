@@ -13,6 +13,8 @@ hand-scheduled chain, not an autograd graph).
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Callable, List, Optional
 
@@ -57,6 +59,11 @@ class UNetEngine:
         # side-stream weight gradients: measured SLOWER on MI355X (485 vs 528 tiles/s fp32, 1505 vs 1566 bf16): the
         # co-resident wgrad / dgrad workgroups halve each other's occupancy and share the matrix pipe — off by default
         self.overlap_wgrad = False
+        # BatchNorm-backward reduction of a block-output layer inside the fp32 gradient-JOIN epilogue: measured slower
+        # than the separate pass (526 vs 530 tiles/s, same box: 48 extra loads per lane in the read-modify-write
+        # epilogue); the bf16 path keeps it (its join epilogue is LDS-staged, +0.5 %).  Kernel support stays tested.
+        self.fuse_join_fp32 = False
+        self._fuse_bn = not os.environ.get("DT_NO_BN_FUSE")   # A/B switch for the plain fused reductions
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, name: str, numel: int, dtype=torch.float32, device=None) -> torch.Tensor:
@@ -610,16 +617,16 @@ class UNetEngine:
                                                 _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                                 _stream()), "dt_conv2d_wgrad_bf16")
 
-        def dgrad_bn(c, dy, Hh, Ww, out0, bn_conv, y):
+        def dgrad_bn(c, dy, Hh, Ww, out0, bn_conv, y, act=None):
             """stride-1 data gradient of conv c with the BatchNorm-backward reduction of bn_conv fused (fp32 twin:
-            _dgrad_bn) -> (red, P)"""
+            _dgrad_bn; act = stored block output -> gradient join) -> (red, P)"""
             Cq = bn_conv.cout
-            desc = self._desc(B, Hh, Ww, c.cout, 0, 0, Hh, Ww, c.cin, c.k, 1, c.k - 1 - c.pad)
+            desc = self._desc(B, Hh, Ww, c.cout, 0, 0, Hh, Ww, c.cin, c.k, 1, c.k - 1 - c.pad, 0, 0 if act is None else 1)
             P = lib.dt_conv2d_bf16_stat_rows(C.byref(desc))
             red = self._buf("bn_red_fused", lib.dt_bn_stats_floats(P, Cq), device=dev)
-            asc, ash = self._ss(bn_conv, bnws)
+            asc, ash = self._ss(bn_conv, bnws) if act is None else (None, None)
             fuse = _lib.BnBwdFuse(_p(y), _p(bnws[bn_conv.bn_off:bn_conv.bn_off + Cq]),
-                                  _p(bnws[nb + bn_conv.bn_off:nb + bn_conv.bn_off + Cq]), _p(asc), _p(ash))
+                                  _p(bnws[nb + bn_conv.bn_off:nb + bn_conv.bn_off + Cq]), _p(asc), _p(ash), _p(act))
             _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(desc), _p(dy), _p(wbd[c.w_off:c.w_off + c.w_size]), _p(out0),
                                                  _p(red), C.byref(fuse), _stream()), "dt_conv2d_bf16_bn_bwd")
             return red, P
@@ -702,12 +709,12 @@ class UNetEngine:
                 if gin is None:
                     gin = torch.empty(r["x"].shape, dtype=bf, device=dev)
                 if blk.down is None:
-                    dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gin, dres_acc=gin_has)
+                    dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gin, dres_acc=gin_has, reduced=g_red)
                     gin_has = True
                     dyd = None
                 else:
                     gd = torch.empty(r["out"].shape, dtype=bf, device=dev)
-                    dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gd)
+                    dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gd, reduced=g_red)
                     dyd = bn_bwd(blk.down, gd, None, r["yd"])
                     del gd
                 wgrad(blk.conv2, r["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
@@ -717,7 +724,13 @@ class UNetEngine:
                 dy1 = bn_bwd(blk.conv1, dz1, None, r["y1"], virtual_act=True, reduced=red1)
                 del dz1
                 wgrad(blk.conv1, r["x"], None, 0, Hin, Win, dy1)
-                dgrad(blk.conv1, dy1, Hin, Win, gin, acc=gin_has)
+                g_red = None
+                if bi > 0 and blk.down is None and gin_has:
+                    # last writer of block bi-1's output gradient: its bn2 reduction (mask: stored output) rides along
+                    rp = S[f"L{li}B{bi - 1}"]
+                    g_red = dgrad_bn(blk.conv1, dy1, Hin, Win, gin, blocks[bi - 1].conv2, rp["y2"], act=rp["out"])
+                else:
+                    dgrad(blk.conv1, dy1, Hin, Win, gin, acc=gin_has)
                 gin_has = True
                 del dy1
                 if dyd is not None:
@@ -809,19 +822,21 @@ class UNetEngine:
                                             _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                             _stream()), "dt_conv2d_wgrad")
 
-    def _dgrad_bn(self, c: ConvSpec, dy, B, H, W, out0, bn_conv: ConvSpec, y, bnws):
+    def _dgrad_bn(self, c: ConvSpec, dy, B, H, W, out0, bn_conv: ConvSpec, y, bnws, act=None):
         """stride-1 data gradient of conv `c` into out0 with the BatchNorm-backward reduction of `bn_conv` (the layer
-        whose raw output `y` has out0's shape, activation virtual) fused into the epilogue -> (red, P) for _bn_bwd"""
+        whose raw output `y` has out0's shape) fused into the epilogue -> (red, P) for _bn_bwd.  act None: plain store,
+        virtual activation (mask from y); act = stored block output: the gradient is ADDED to out0 (join) and the
+        sums are taken over the joined tensor."""
         Cc = bn_conv.cout
         assert c.stride == 1 and c.cin == Cc and tuple(y.shape) == tuple(out0.shape)
         wd = self._wd_all[c.w_off:c.w_off + c.w_size]
-        desc = self._desc(B, H, W, c.cout, 0, 0, H, W, c.cin, c.k, 1, c.k - 1 - c.pad)
+        desc = self._desc(B, H, W, c.cout, 0, 0, H, W, c.cin, c.k, 1, c.k - 1 - c.pad, 0, 0 if act is None else 1)
         P = self.lib.dt_conv2d_stat_rows(C.byref(desc))
         red = self._buf("bn_red_fused", self.lib.dt_bn_stats_floats(P, Cc), device=dy.device)
         nb = self.spec.n_bn_channels
-        asc, ash = self._ss(bn_conv, bnws)
+        asc, ash = self._ss(bn_conv, bnws) if act is None else (None, None)
         fuse = _lib.BnBwdFuse(_p(y), _p(bnws[bn_conv.bn_off: bn_conv.bn_off + Cc]),
-                              _p(bnws[nb + bn_conv.bn_off: nb + bn_conv.bn_off + Cc]), _p(asc), _p(ash))
+                              _p(bnws[nb + bn_conv.bn_off: nb + bn_conv.bn_off + Cc]), _p(asc), _p(ash), _p(act))
         prof = self.profile
         if prof is not None:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -832,7 +847,8 @@ class UNetEngine:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             flops = 2.0 * desc.ksize ** 2 * desc.C0 * desc.Cout * desc.Ho * desc.Wo * desc.B
-            nbytes = 4.0 * desc.B * desc.Ho * desc.Wo * (desc.C0 + 2 * desc.Cout) + 4.0 * desc.ksize ** 2 * desc.C0 * desc.Cout
+            nbytes = 4.0 * desc.B * desc.Ho * desc.Wo * (desc.C0 + (2 if act is None else 4) * desc.Cout) + \
+                4.0 * desc.ksize ** 2 * desc.C0 * desc.Cout
             prof.append((self._conv_kernel_name(desc, False), flops, e0, e1, nbytes))
         return red, P
 
@@ -892,7 +908,10 @@ class UNetEngine:
                                reduced=g_red)
             self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty_like(d["y1"])
-            red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, d["y1"], bnws)
+            if self._fuse_bn:
+                red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, d["y1"], bnws)
+            else:
+                red1 = self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
             del dy2
             dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, d["y1"], virtual_act=True, reduced=red1)
             del dz1
@@ -909,7 +928,7 @@ class UNetEngine:
             del dy1
             g = torch.empty_like(d["x"])
             g_red = None
-            if i >= 1 and d["x_virtual"]:
+            if i >= 1 and d["x_virtual"] and self._fuse_bn:
                 # g is the gradient of relu(bn(y2)) of decoder block i-1 (never stored): its BatchNorm-backward
                 # reduction rides along in the pass that writes g
                 pb = sp.decoder[i - 1].conv2
@@ -947,22 +966,33 @@ class UNetEngine:
                     gin = torch.empty_like(r["x"])
                 if blk.down is None:
                     dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, r["out"], r["y2"], dres=gin,
-                                       dres_acc=gin_has)
+                                       dres_acc=gin_has, reduced=g_red)
                     gin_has = True
                     dyd = None
                 else:
                     gd = torch.empty_like(r["out"])
-                    dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, r["out"], r["y2"], dres=gd)
+                    dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, r["out"], r["y2"], dres=gd, reduced=g_red)
                     dyd = self._bn_bwd(blk.down, params, grads, bnws, gd, None, r["yd"])
                     del gd
                 self._wgrad(blk.conv2, grads, r["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
                 dz1 = torch.empty_like(r["y1"])
-                red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, r["y1"], bnws)
+                if self._fuse_bn:
+                    red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, r["y1"], bnws)
+                else:
+                    red1 = self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
                 del dy2
                 dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, r["y1"], virtual_act=True, reduced=red1)
                 del dz1
                 self._wgrad(blk.conv1, grads, r["x"], None, 0, B, Hin, Win, dy1)
-                self._dgrad(blk.conv1, params, dy1, B, Hin, Win, gin, acc=gin_has)
+                g_red = None
+                if self.fuse_join_fp32 and bi > 0 and blk.down is None and gin_has:
+                    # gin becomes the output gradient of block bi-1: this join is its last writer, so the
+                    # BatchNorm-backward sums of that block's bn2 (mask: its stored output) ride along
+                    rp = S[f"L{li}B{bi - 1}"]
+                    g_red = self._dgrad_bn(blk.conv1, dy1, B, Hin, Win, gin, blocks[bi - 1].conv2, rp["y2"], bnws,
+                                           act=rp["out"])
+                else:
+                    self._dgrad(blk.conv1, params, dy1, B, Hin, Win, gin, acc=gin_has)
                 gin_has = True
                 del dy1
                 if dyd is not None:

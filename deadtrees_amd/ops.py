@@ -302,33 +302,38 @@ def confusion_matrix(pred, target, lu=None, K=2, counts=None):
     return counts, err
 
 
-def conv2d_bn_bwd(src0, w_hwio, y, mean, invstd, act_scale, act_shift):
+def conv2d_bn_bwd(src0, w_hwio, y, mean, invstd, act_scale=None, act_shift=None, act=None, join_into=None):
     """3x3 stride-1 conv (a data gradient) whose epilogue also produces the BatchNorm-backward partial sums of the
-    layer with raw output `y` (same shape as the result).  -> (out [B,H,W,Cout], red [2,P,Cout])"""
-    _gpu(src0, w_hwio, y, mean, invstd, act_scale, act_shift)
+    layer with raw output `y` (same shape as the result).  Virtual activation: give act_scale/act_shift; block
+    output: give the stored activation `act` and the tensor `join_into` the gradient is ADDED to.
+    -> (out [B,H,W,Cout], red [2,P,Cout])"""
+    _gpu(src0, w_hwio, y, mean, invstd, act_scale, act_shift, act, join_into)
     lib = _lib.load()
     B, H, W, C0 = src0.shape
     Cout = w_hwio.shape[-1]
-    d = conv_desc(B, H, W, C0, 0, 0, Cout, 3, 1, 1)
+    d = conv_desc(B, H, W, C0, 0, 0, Cout, 3, 1, 1, 0, 1 if join_into is not None else 0)
     P = lib.dt_conv2d_stat_rows(C.byref(d))
     red = torch.empty(lib.dt_bn_stats_floats(P, Cout), dtype=torch.float32, device=src0.device)
-    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=src0.device)
-    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift))
+    out = join_into if join_into is not None else torch.empty((B, H, W, Cout), dtype=torch.float32, device=src0.device)
+    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift), _p(act))
     _lib.check(lib.dt_conv2d_bn_bwd(C.byref(d), _p(src0), _p(w_hwio.contiguous()), _p(out), _p(red), C.byref(fuse),
                                     _st()), "dt_conv2d_bn_bwd")
     return out, red[:2 * P * Cout].view(2, P, Cout)
 
 
-def conv2d_bf16_bn_bwd(src0, w_packed, cout, y, mean, invstd, act_scale, act_shift):
-    """bf16 twin of conv2d_bn_bwd (src0, y bf16 NHWC; w_packed from pack_weights_bf16) -> (out bf16, red [2,P,Cout])"""
-    _gpu(src0, w_packed, y, mean, invstd, act_scale, act_shift)
+def conv2d_bf16_bn_bwd(src0, w_packed, cout, y, mean, invstd, act_scale=None, act_shift=None, act=None,
+                       join_into=None):
+    """bf16 twin of conv2d_bn_bwd (src0, y, act, join_into bf16 NHWC; w_packed from pack_weights_bf16)
+    -> (out bf16, red [2,P,Cout])"""
+    _gpu(src0, w_packed, y, mean, invstd, act_scale, act_shift, act, join_into)
     lib = _lib.load()
     B, H, W, C0 = src0.shape
-    d = conv_desc(B, H, W, C0, 0, 0, cout, 3, 1, 1)
+    d = conv_desc(B, H, W, C0, 0, 0, cout, 3, 1, 1, 0, 1 if join_into is not None else 0)
     P = lib.dt_conv2d_bf16_stat_rows(C.byref(d))
     red = torch.empty(lib.dt_bn_stats_floats(P, cout), dtype=torch.float32, device=src0.device)
-    out = torch.empty((B, H, W, cout), dtype=torch.bfloat16, device=src0.device)
-    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift))
+    out = join_into if join_into is not None else torch.empty((B, H, W, cout), dtype=torch.bfloat16,
+                                                              device=src0.device)
+    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift), _p(act))
     _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(d), _p(src0), _p(w_packed), _p(out), _p(red), C.byref(fuse), _st()),
                "dt_conv2d_bf16_bn_bwd")
     return out, red[:2 * P * cout].view(2, P, cout)

@@ -159,6 +159,9 @@ typedef struct dt_bn_bwd_fuse {
   const float* invstd;
   const float* act_scale;  /* scale / shift of that BatchNorm (its ReLU mask is recomputed from y) */
   const float* act_shift;
+  const float* act;        /* optional: the STORED activation (block outputs, relu(bn(y) + identity)); when given the
+                              mask is act > 0 and act_scale / act_shift are not read.  With it the convolution may be a
+                              gradient join (desc->accumulate = 1): the sums are taken over out0 AFTER the add. */
 } dt_bn_bwd_fuse;
 int dt_conv2d_bn_bwd(const dt_conv_desc* desc, const float* src0, const float* w, float* out0, float* red,
                      const dt_bn_bwd_fuse* fuse, void* stream);

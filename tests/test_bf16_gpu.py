@@ -336,3 +336,28 @@ def test_stem_weight_gradient_on_bf16_kernels(B, H, W, Cin):
     dw = ops.stem_wgrad_bf16(x.permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV))
     got = dw.cpu().permute(3, 2, 0, 1).double()
     assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 3e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 40, 64, 64), (2, 9, 70, 128, 96), (16, 120, 128, 48, 128)])
+def test_conv_bf16_gradient_join_with_fused_bn_backward_reduction(B, H, W, Cin, Cout):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 5 + Cin + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g).to(BF)
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5).to(BF)
+    y = (torch.randn((B, Cout, H, W), generator=g) * 1.5 + 0.2).to(BF)
+    z = torch.relu(torch.randn((B, Cout, H, W), generator=g)).to(BF)
+    base = torch.randn((B, Cout, H, W), generator=g).to(BF)
+    mean = y.float().mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(y.float().var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)  # noqa: E731
+    wp = ops.pack_weights_bf16(w.float().permute(2, 3, 1, 0).contiguous().to(DEV))
+    plain, _, _ = ops.conv2d_bf16(nh(x), wp, 3, 1, 1, Cout, out0=nh(base), accumulate=True)
+    out, red = ops.conv2d_bf16_bn_bwd(nh(x), wp, Cout, nh(y), mean.to(DEV), invstd.to(DEV), act=nh(z), join_into=nh(base))
+    assert torch.equal(out, plain)
+    dz = out.float().cpu().permute(0, 3, 1, 2).double()
+    gm = torch.where(z.double() > 0, dz, torch.zeros_like(dz))
+    xh = (y.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    sums = red.sum(dim=1).cpu().double()
+    scale = float(gm.abs().sum(dim=(0, 2, 3)).max()) + 1.0
+    assert float((sums[0] - gm.sum(dim=(0, 2, 3))).abs().max()) <= 3e-5 * scale
+    assert float((sums[1] - (gm * xh).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * scale

@@ -375,3 +375,32 @@ def test_upsample_backward_with_fused_bn_reduction(dtype, B, H, W, C):
     scale = float(gm.abs().sum(dim=(0, 1, 2)).max()) + 1.0
     assert float((sums[0] - gm.sum(dim=(0, 1, 2))).abs().max()) <= 3e-5 * scale
     assert float((sums[1] - (gm * xh).sum(dim=(0, 1, 2))).abs().max()) <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 40, 64, 64), (2, 9, 70, 128, 96), (1, 16, 16, 256, 256)])
+def test_conv_gradient_join_with_fused_bn_backward_reduction(B, H, W, Cin, Cout):
+    """dt_conv2d_bn_bwd on a gradient join (accumulate) with the mask taken from a stored activation: the joined tensor
+    equals dt_conv2d(accumulate) bit for bit; the sums are the BatchNorm-backward reduction of the JOINED gradient."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 5 + Cin + Cout)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    y = torch.randn((B, Cout, H, W), generator=g) * 1.5 + 0.2
+    z = torch.relu(torch.randn((B, Cout, H, W), generator=g))          # stored block output (about half zeros)
+    base = torch.randn((B, Cout, H, W), generator=g)
+    mean = y.mean(dim=(0, 2, 3))
+    invstd = 1.0 / torch.sqrt(y.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    xg, wg = nhwc(x), hwio(w)
+    plain, _, _ = ops.conv2d(xg, wg, 3, 1, 1, out0=nhwc(base), accumulate=True)
+    out, red = ops.conv2d_bn_bwd(xg, wg, nhwc(y), mean.to(DEV), invstd.to(DEV), act=nhwc(z), join_into=nhwc(base))
+    assert torch.equal(out, plain)
+    dz = to_nchw(out)
+    gm = torch.where(z.double() > 0, dz, torch.zeros_like(dz))
+    xh = (y.double() - mean.double()[None, :, None, None]) * invstd.double()[None, :, None, None]
+    sums = red.sum(dim=1).cpu().double()
+    scale = float(gm.abs().sum(dim=(0, 2, 3)).max()) + 1.0
+    assert float((sums[0] - gm.sum(dim=(0, 2, 3))).abs().max()) <= 2e-5 * scale
+    assert float((sums[1] - (gm * xh).sum(dim=(0, 2, 3))).abs().max()) <= 6e-5 * scale
+    with pytest.raises(RuntimeError):          # a join needs the stored activation
+        ops.conv2d_bn_bwd(xg, wg, nhwc(y), mean.to(DEV), invstd.to(DEV), act_scale=mean.to(DEV), act_shift=mean.to(DEV),
+                          join_into=nhwc(base))
