@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the whole training step as one HIP graph (auto: single-GPU bf16, where the step "
                          "is shorter than the Python launch path; multi-GPU runs only with --graph on)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra configs[2] (bf16, B=64) leg of the default run")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE configs[1] (headline); bf16 = configs[2] (bf16 storage, fp32 accumulate)")
     ap.add_argument("--mode", choices=["train", "infer"], default="train",
@@ -75,21 +76,73 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from deadtrees_amd.network.unet import UNetHIP
+
+    if args.mode == "infer":
+        model = UNetHIP(in_channels=3, classes=2)
+        model.reset_parameters(seed=0)
+        model.to(dev)
+        return infer_bench(args, model, dev, world, rank, distributed)
+
+    ctx = dict(dev=dev, world=world, rank=rank, distributed=distributed)
+    out = train_leg(args, ctx, args.precision, args.batch, headline=True)
+    # configs[2] travels in the SAME JSON line as a leg (the headline stays configs[1]): bf16 storage / fp32 accumulate,
+    # batch 64 per GPU, its own dominant-kernel roofline.  A failure of the leg must not cost the headline.
+    if args.precision == "fp32" and not args.no_legs:
+        try:
+            leg = train_leg(args, ctx, "bf16", 64, headline=False)
+            out["legs"] = {"bf16_b64": {k: leg[k] for k in ("value", "unit", "ms_per_step", "dtype", "config", "loss",
+                                                            "hip_graph", "whole_net", "roofline")}}
+        except Exception as e:  # noqa: BLE001
+            out["legs"] = {"bf16_b64": {"error": f"{type(e).__name__}: {e}"}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args):
+    """the oracle port of the reference's CPU training step (oracle/train_ref.py) on this box's host cores: all
+    cores of the box's CPU share (>= 5 timed steps, median) and one thread (2 timed steps) — a reported baseline"""
+    import torch
+    from deadtrees_amd.data.synthetic import synth_batch
+    from oracle.train_ref import time_cpu_baseline
+    S = args.size
+    cimg, cmask = synth_batch(2, S, S, 3, 2, seed=1234)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
+    steps = max(args.cpu_steps, 5)
+    res = time_cpu_baseline(cimg, cmask, steps=steps, warmup=1, threads=cores)
+    one = time_cpu_baseline(cimg, cmask, steps=2, warmup=1, threads=1)
+    return {"value": round(res["tiles_per_s"], 3), "unit": "tiles/s", "cores": res["threads"], "kind": "port",
+            "single_thread_value": round(one["tiles_per_s"], 3),
+            "sample": f"oracle port of the reference CPU path (torch {torch.__version__} CPU, B=2, {S}x{S}, "
+                      f"{steps} timed steps after 1 warm-up, median; single thread: 2 timed steps)"}
+
+
+def train_leg(args, ctx, precision, B, headline):
+    """one timed training configuration -> result dict (the bench.py JSON contract keys + roofline block)"""
+    import torch
+    import torch.distributed as dist
     from deadtrees_amd.data.synthetic import synth_batch
     from deadtrees_amd.network.unet import UNetHIP
     from deadtrees_amd.trainer import HipTrainer
-
-    B, S = args.batch, args.size
+    dev, world, rank, distributed = ctx["dev"], ctx["world"], ctx["rank"], ctx["distributed"]
+    S = args.size
     model = UNetHIP(in_channels=3, classes=2)
     model.reset_parameters(seed=0)
     model.to(dev)
-    if args.mode == "infer":
-        return infer_bench(args, model, dev, world, rank, distributed)
     # auto: graph replay only where the step is launch-bound (single-GPU bf16); fp32 and every multi-GPU run stay
     # eager by default so that the 1/2/4/8-GPU numbers come from one code path ("on" forces it, RCCL included)
-    use_graph = args.graph == "on" or (args.graph == "auto" and args.precision == "bf16" and not distributed)
+    use_graph = args.graph == "on" or (args.graph == "auto" and precision == "bf16" and not distributed)
     tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed,
-                    precision=args.precision, graph=use_graph)
+                    precision=precision, graph=use_graph)
     tr.broadcast_parameters(0)
     img, mask = synth_batch(B, S, S, 3, 2, seed=1234 + rank)
     img, mask = img.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
@@ -133,7 +186,7 @@ def main():
     # PCIe-inclusive rate (never `value`): the batch arrives in pinned host memory every step (fp32 image + int64
     # mask, what the reference's loader hands to Lightning) on a copy stream, overlapped with the previous step
     pcie = None
-    if rank == 0 and not distributed:
+    if rank == 0 and not distributed and headline:
         tr.use_graph = use_graph
         himg, hmask = img.cpu().pin_memory(), mask.cpu().pin_memory()
         bufs = [(torch.empty_like(img), torch.empty_like(mask)) for _ in range(2)]
@@ -193,15 +246,15 @@ def main():
             except Exception:
                 pass
     per_gpu_tiles_s = B * args.steps / wall * (S / 512.0) ** 2   # 512x512-equivalent tiles for the FLOP/byte model
-    peak_tf = PEAK_FP32_TFLOPS if args.precision == "fp32" else 2500.0   # dense bf16 MFMA peak
-    bytes_per_tile = BYTES_PER_TILE_TRAIN if args.precision == "fp32" else 462.2e6
+    peak_tf = PEAK_FP32_TFLOPS if precision == "fp32" else 2500.0   # dense bf16 MFMA peak
+    bytes_per_tile = BYTES_PER_TILE_TRAIN if precision == "fp32" else 462.2e6
     out = {
         "metric": f"{S}x{S} RGB tiles/sec (train fwd+bwd)", "value": round(value, 2), "unit": "tiles/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
-        "config": {"workload": ("configs[1]" if args.precision == "fp32" else "configs[2]") +
-                               f": reference U-Net (smp Unet/resnet34 topology) {args.precision} train step, "
+        "dtype": "f32" if precision == "fp32" else "bf16 (fp32 accumulate, fp32 master weights)", "data": "synthetic",
+        "config": {"workload": ("configs[1]" if precision == "fp32" else "configs[2]") +
+                               f": reference U-Net (smp Unet/resnet34 topology) {precision} train step, "
                                f"batch {B}/GPU, {S}x{S}x3 tiles, GDICE+FOCAL, clip 0.5, Adam 3e-4",
                    "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
         "loss": round(float(loss), 6), "hip_graph": use_graph,
@@ -212,24 +265,12 @@ def main():
                       "conv_fwd_dgrad_share_of_step": round((conv_time / prof_steps) / step_s, 4)},
         "roofline": roof,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.train_ref import time_cpu_baseline
-        cimg, cmask = synth_batch(2, S, S, 3, 2, seed=1234)
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
-        cores = min(cores, 16)   # a 1-GPU box's CPU share is 16 cores; more threads only oversubscribe
-        res = time_cpu_baseline(cimg, cmask, steps=args.cpu_steps, warmup=1, threads=cores)
-        out["cpu_baseline"] = {"value": round(res["tiles_per_s"], 3), "unit": "tiles/s", "cores": res["threads"],
-                               "kind": "port",
-                               "sample": f"oracle port of the reference CPU path (torch {torch.__version__} CPU, "
-                                         f"B=2, {S}x{S}, {args.cpu_steps} timed steps after 1 warm-up, median)"}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if distributed:
-        dist.destroy_process_group()
+    # free this leg's buffers (saved activations, graph pool) before the next leg allocates its own
+    del tr, model, img, mask
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
 
 
 def infer_bench(args, model, dev, world, rank, distributed):

@@ -1,0 +1,2 @@
+"""reference deadtrees/data/deadtreedata.py -> deadtrees_amd.data.deadtreedata"""
+from deadtrees_amd.data.deadtreedata import DeadtreeDatasetConfig, DeadtreesDataModule, val_transform  # noqa: F401

@@ -33,6 +33,10 @@ _P = C.POINTER(ConvDesc)
 class BnBwdFuse(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("y", "mean", "invstd", "act_scale", "act_shift", "act")]
 
+class LossCfg(C.Structure):
+    _fields_ = [("dice_kind", I32), ("use_boundary", I32), ("use_focal", I32), ("boundary_weight", F32), ("gamma", F32)]
+
+
 # name -> (restype, argtypes).  Must list every symbol of include/deadtrees_hip.h
 # (tests/test_abi.py cross-checks this table against the header).
 SIGNATURES = {
@@ -55,6 +59,9 @@ SIGNATURES = {
     "dt_bn_bwd_reduce": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, I64, C.c_int, c_f]),
     "dt_bn_bwd_apply": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f, C.c_int,
                                   I64, C.c_int, c_f]),
+    "dt_bn_bwd_apply_frozen": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, c_f, c_f, c_f, c_f,
+                                         C.c_int, I64, C.c_int, c_f]),
+    "dt_bn_eval_stats": (C.c_int, [c_f, c_f, F32, C.c_int, c_f, c_f, c_f]),
     "dt_maxpool3x3s2": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_maxpool3x3s2_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_upsample2x_bwd": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
@@ -71,6 +78,8 @@ SIGNATURES = {
     "dt_gwdice_posgrad": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, F32, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_seg_loss_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_seg_loss_algebra": (C.c_int, [c_f, C.POINTER(LossCfg), C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f, c_f, c_f, c_f,
+                                      c_f, c_f]),
     "dt_confusion_matrix": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, I64, c_f, c_f, c_f]),
     "dt_augment_normalize_u8": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_float), C.POINTER(C.c_float), c_f]),
@@ -114,6 +123,8 @@ SIGNATURES = {
     "dt_sumsq": (C.c_int, [c_f, I64, c_f, c_f]),
     "dt_clip_coef": (C.c_int, [c_f, C.c_int, F32, F32, c_f, c_f, c_f]),
     "dt_adam_step": (C.c_int, [c_f, c_f, c_f, c_f, I64, F32, F32, F32, F32, F32, F32, c_f, c_f, c_f]),
+    "dt_skip_from_loss": (C.c_int, [c_f, c_f, c_f]),
+    "dt_adam_advance": (C.c_int, [c_f, c_f, c_f, F32, F32, c_f, c_f]),
     "dt_adam_step_dev": (C.c_int, [c_f, c_f, c_f, c_f, I64, c_f, F32, F32, F32, c_f, c_f, c_f]),
 }
 

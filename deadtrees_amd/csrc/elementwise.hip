@@ -139,6 +139,23 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
   }
 }
 
+__global__ void bn_eval_stats_kernel(const float* rm, const float* rv, float eps, int C, float* mean, float* invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    mean[c] = rm[c];
+    invstd[c] = 1.f / sqrtf(rv[c] + eps);
+  }
+}
+
+extern "C" int dt_bn_eval_stats(const float* rm, const float* rv, float eps, int C, float* mean, float* invstd,
+                                void* stream) {
+  DT_REQUIRE(rm && rv && mean && invstd && C > 0, "bn_eval_stats: bad args");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(dt_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rm, rv, eps, C,
+                     mean, invstd);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 extern "C" int dt_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                                  float eps, int C, float* scale, float* shift, void* stream) {
   DT_REQUIRE(gamma && beta && rm && rv && scale && shift && C > 0, "bn_eval_affine: bad args");
@@ -410,10 +427,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
-extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
-                               const float* invstd, const float* gamma, const float* act_scale,
-                               const float* act_shift, float* red, int P, float* dgamma, float* dbeta, float* dy,
-                               float* dres, int dres_accumulate, int64_t n_pix, int C, void* stream) {
+static int bn_bwd_apply_impl(const float* dout, const float* out_act, const float* y, const float* mean,
+                             const float* invstd, const float* gamma, const float* act_scale, const float* act_shift,
+                             float* red, int P, float* dgamma, float* dbeta, float* dy, float* dres, int dres_accumulate,
+                             int64_t n_pix, int C, void* stream, bool frozen) {
   DT_REQUIRE(dout && y && mean && invstd && gamma && red && dgamma && dbeta && dy && n_pix > 0 && C > 0 &&
                  (C & 3) == 0 && P > 0,
              "bn_bwd_apply: bad args");
@@ -421,11 +438,29 @@ extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const fl
   int rc0 = dt_bn_bwd_finish_sums(red, P, C, dgamma, dbeta, st);
   if (rc0 != DT_OK) return rc0;
   const int64_t n4 = n_pix * C / 4;
+  // frozen statistics (eval-mode BatchNorm): mean / invstd are constants of the layer, so the two batch-mean terms
+  // of the training-mode formula vanish -> inv_count = 0 turns dy into g * gamma * invstd
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, (const f32x4*)dout,
                      (const f32x4*)out_act, (const f32x4*)y, mean, invstd, gamma, dgamma, dbeta, act_scale, act_shift,
-                     (f32x4*)dy, (f32x4*)dres, dres_accumulate, n4, C / 4, (float)(1.0 / (double)n_pix));
+                     (f32x4*)dy, (f32x4*)dres, dres_accumulate, n4, C / 4, frozen ? 0.f : (float)(1.0 / (double)n_pix));
   DT_LAUNCH_CHECK();
   return DT_OK;
+}
+
+extern "C" int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, const float* mean,
+                               const float* invstd, const float* gamma, const float* act_scale,
+                               const float* act_shift, float* red, int P, float* dgamma, float* dbeta, float* dy,
+                               float* dres, int dres_accumulate, int64_t n_pix, int C, void* stream) {
+  return bn_bwd_apply_impl(dout, out_act, y, mean, invstd, gamma, act_scale, act_shift, red, P, dgamma, dbeta, dy, dres,
+                           dres_accumulate, n_pix, C, stream, false);
+}
+
+extern "C" int dt_bn_bwd_apply_frozen(const float* dout, const float* out_act, const float* y, const float* mean,
+                                      const float* invstd, const float* gamma, const float* act_scale,
+                                      const float* act_shift, float* red, int P, float* dgamma, float* dbeta, float* dy,
+                                      float* dres, int dres_accumulate, int64_t n_pix, int C, void* stream) {
+  return bn_bwd_apply_impl(dout, out_act, y, mean, invstd, gamma, act_scale, act_shift, red, P, dgamma, dbeta, dy, dres,
+                           dres_accumulate, n_pix, C, stream, true);
 }
 
 // ------------------------------------------------------------------ max-pool 3x3 / stride 2 / pad 1

@@ -537,6 +537,123 @@ extern "C" int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const
   return DT_OK;
 }
 
+// ------------------------------------------------------------------ scalar algebra of the compound loss
+// Everything SemSegment.calculate_loss / log_metrics (segmodel.py:169-208) does AFTER the big reductions — class
+// weights of gdl.py:15-23, the dice / focal / boundary quotients of losses.py:187-291, gwdl.py:110-138, both smp
+// F-scores — on the [B][K][NACC] sums, in fp64, by one thread: ~60 tiny ATen launches per step become one, and
+// the coefficients the backward pass needs (coef, wfocal, wbound, wass_a, wass_c) never leave the device.
+#define GW_EPS 2.220446049250313e-16   // np.spacing(1), loss/gwdl.py:92
+#define LOSS_EPS 1e-10                 // loss/losses.py:19
+__global__ void seg_loss_algebra_kernel(const double* __restrict__ acc, dt_loss_cfg cfg, int B, int K, double HW,
+                                        float* __restrict__ parts, float* __restrict__ coef,
+                                        float* __restrict__ wfocal, float* __restrict__ wbound,
+                                        float* __restrict__ wass_a, float* __restrict__ wass_c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  auto A = [&](int b, int k, int j) { return acc[((size_t)b * K + k) * DT_LOSS_NACC + j]; };
+  for (int i = 0; i < B * K * 2; ++i) coef[i] = 0.f;
+  double dice = 0.0;
+  if (cfg.dice_kind == 2) {   // GWDICE, weighting_mode "default": alpha = 0 for background
+    for (int b = 0; b < B; ++b) {
+      double gtp = 0.0, ae = 0.0;
+      for (int k = 0; k < K; ++k) {
+        if (k > 0) gtp += A(b, k, 9);
+        ae += A(b, k, 8);
+      }
+      const double den = 2.0 * gtp + ae + GW_EPS;
+      dice += 1.0 - (2.0 * gtp + GW_EPS) / den;
+      if (wass_a) wass_a[b] = (float)(2.0 * ae / (den * den) / B);
+      if (wass_c) wass_c[b] = (float)((2.0 * gtp + GW_EPS) / (den * den) / B);
+    }
+    dice /= B;
+  } else if (cfg.dice_kind == 0) {   // GDICE: whole-batch class weights from integer counts
+    double N = 0.0, D = 0.0, w[HEAD_MAXK];
+    for (int k = 0; k < K; ++k) {
+      double S = 0.0, pt = 0.0, ps = 0.0;
+      for (int b = 0; b < B; ++b) {
+        S += A(b, k, 0);
+        pt += A(b, k, 1);
+        ps += A(b, k, 2);
+      }
+      w[k] = 1.0 / (S * S + 1e-9);
+      N += w[k] * pt;
+      D += w[k] * (S + ps);
+    }
+    dice = 1.0 - 2.0 * (N + 1e-9) / (D + 1e-9);
+    for (int b = 0; b < B; ++b)
+      for (int k = 0; k < K; ++k) {
+        coef[((size_t)b * K + k) * 2] = (float)(-2.0 * w[k] / (D + 1e-9));
+        coef[((size_t)b * K + k) * 2 + 1] = (float)(2.0 * w[k] * (N + 1e-9) / ((D + 1e-9) * (D + 1e-9)));
+      }
+  } else if (cfg.dice_kind == 1) {   // DICE: per sample, non-background classes
+    const double nfg = K - 1;
+    for (int b = 0; b < B; ++b)
+      for (int k = 1; k < K; ++k) {
+        const double I = A(b, k, 1), U = A(b, k, 2) + A(b, k, 0);
+        dice += 1.0 - (2.0 * I + LOSS_EPS) / (U + LOSS_EPS);
+        coef[((size_t)b * K + k) * 2] = (float)(-2.0 / (U + LOSS_EPS) / (B * nfg));
+        coef[((size_t)b * K + k) * 2 + 1] = (float)((2.0 * I + LOSS_EPS) / ((U + LOSS_EPS) * (U + LOSS_EPS)) / (B * nfg));
+      }
+    dice /= (B * nfg);
+  }
+  double total = dice, boundary = 0.0, focal = 0.0;
+  for (int k = 0; k < K; ++k) wbound[k] = 0.f;
+  if (cfg.use_boundary) {
+    const double scale = 1.0 / ((double)B * (K - 1) * HW);
+    for (int b = 0; b < B; ++b)
+      for (int k = 1; k < K; ++k) boundary += A(b, k, 5);
+    boundary *= scale;
+    total += (double)cfg.boundary_weight * boundary;
+    for (int k = 1; k < K; ++k) wbound[k] = (float)((double)cfg.boundary_weight * scale);
+  }
+  double cnt = 0.0, foc = 0.0, ce = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < K; ++k) {
+      cnt += A(b, k, 0);
+      foc += A(b, k, 3);
+      ce += A(b, k, 4);
+    }
+  wfocal[0] = 0.f;
+  wfocal[1] = cfg.gamma;
+  if (cfg.use_focal) {
+    const double M = cnt + LOSS_EPS;
+    focal = -foc / M;
+    total += focal;
+    wfocal[0] = (float)(1.0 / M);
+  }
+  auto fscore = [&](int k0) {
+    double tps = 0.0, prs = 0.0, gts = 0.0;
+    for (int b = 0; b < B; ++b)
+      for (int k = k0; k < K; ++k) {
+        tps += A(b, k, 6);
+        prs += A(b, k, 7);
+        gts += A(b, k, 0);
+      }
+    return (2.0 * tps + 1e-7) / (2.0 * tps + (gts - tps) + (prs - tps) + 1e-7);
+  };
+  parts[0] = (float)dice;
+  parts[1] = (float)boundary;
+  parts[2] = (float)focal;
+  parts[3] = (float)(-ce / (cnt + LOSS_EPS));
+  parts[4] = (float)fscore(1);
+  parts[5] = (float)fscore(0);
+  parts[6] = (float)total;
+  parts[7] = (float)total;
+}
+
+extern "C" int dt_seg_loss_algebra(const double* acc, const dt_loss_cfg* cfg, int B, int K, int H, int W, float* parts,
+                                   float* coef, float* wfocal, float* wbound, float* wass_a, float* wass_c,
+                                   void* stream) {
+  DT_REQUIRE(acc && cfg && parts && coef && wfocal && wbound && B > 0 && H > 0 && W > 0, "seg_loss_algebra: bad args");
+  DT_REQUIRE(K >= 2 && K <= HEAD_MAXK, "seg_loss_algebra: K=%d unsupported (2..%d)", K, HEAD_MAXK);
+  DT_REQUIRE(cfg->dice_kind >= 0 && cfg->dice_kind <= 3,
+             "seg_loss_algebra: dice_kind %d (0 GDICE, 1 DICE, 2 GWDICE, 3 none)", cfg->dice_kind);
+  DT_REQUIRE(cfg->dice_kind != 2 || (wass_a && wass_c), "seg_loss_algebra: GWDICE needs wass_a / wass_c");
+  hipLaunchKernelGGL(seg_loss_algebra_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, *cfg, B, K,
+                     (double)H * (double)W, parts, coef, wfocal, wbound, wass_a, wass_c);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ GWDICE cross-sample position sums
 // loss/gwdl.py:180-198 multiplies alpha[B,1,S] with (1 - wass)[B,S]; the shapes broadcast to [B,B,S], so the
 // "generalised true positives" of sample i are  sum_s alpha_i(s) * V(s)  with  V(s) = sum_j (1 - wass_j(s))

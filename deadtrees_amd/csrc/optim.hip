@@ -150,6 +150,39 @@ extern "C" int dt_adam_step(float* p, const float* g, float* m, float* v, int64_
   return DT_OK;
 }
 
+// ---- per-step scalars of the optimiser on the device (no ATen algebra, no host sync, HIP-graph capturable)
+__global__ void skip_from_loss_kernel(const float* __restrict__ loss, int32_t* __restrict__ skip) {
+  const float l = loss[0];
+  skip[0] = (l == l && fabsf(l) != INFINITY) ? 0 : 1;
+}
+
+extern "C" int dt_skip_from_loss(const float* loss, int32_t* skip_flag, void* stream) {
+  DT_REQUIRE(loss && skip_flag, "skip_from_loss: bad args");
+  hipLaunchKernelGGL(skip_from_loss_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss, skip_flag);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+__global__ void adam_advance_kernel(double* __restrict__ t, const int32_t* __restrict__ skip,
+                                    const double* __restrict__ lr, double b1, double b2, float* __restrict__ hyper) {
+  double tt = t[0];
+  if (!(skip && skip[0] != 0)) tt += 1.0;    // a skipped step leaves the step count alone (torch: no optimizer.step)
+  t[0] = tt;
+  const double te = tt < 1.0 ? 1.0 : tt;
+  hyper[0] = (float)lr[0];
+  hyper[1] = (float)(1.0 - pow(b1, te));
+  hyper[2] = (float)(1.0 - pow(b2, te));
+}
+
+extern "C" int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_dev, float beta1, float beta2,
+                               float* hyper, void* stream) {
+  DT_REQUIRE(t_dev && lr_dev && hyper, "adam_advance: bad args");
+  hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t_dev, skip_flag, lr_dev,
+                     (double)beta1, (double)beta2, hyper);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 extern "C" int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                                 float beta1, float beta2, float eps, const float* clipcoef, const int32_t* skip_flag,
                                 void* stream) {

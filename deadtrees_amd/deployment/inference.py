@@ -17,19 +17,40 @@ from ..network.segmodel import SemSegment
 from .. import ops
 
 
-class PyTorchInference:
+class Inference:
+    """reference deployment/inference.py:14-27"""
+
     def __init__(self, model_file: Union[str, Path]) -> None:
         self._model_file = model_file if isinstance(model_file, Path) else Path(model_file)
+
+    @property
+    def model_file(self) -> str:
+        return self._model_file.name
+
+    def run(self, input_tensor):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+
+class ONNXInference(Inference):
+    """reference deployment/inference.py:119-144.  The ONNX export of the reference (scripts/create_onnx.py) cannot
+    carry the HIP kernels and onnxruntime is not part of this build: the class exists so that imports resolve."""
+
+    def __init__(self, model_file) -> None:
+        super().__init__(model_file)
+        if self._model_file.suffix != ".onnx":
+            raise ValueError(f"onnx file expected, but {self._model_file.suffix} received")
+        raise NotImplementedError("ONNX inference is outside the MI355X hot path (SURVEY.md §8b); use PyTorchInference")
+
+
+class PyTorchInference(Inference):
+    def __init__(self, model_file: Union[str, Path]) -> None:
+        super().__init__(model_file)
         if self._model_file.suffix != ".ckpt":
             raise ValueError(f"ckpt file expected, but {self._model_file.suffix} received")
         model = SemSegment.load_from_checkpoint(self._model_file)
         model.eval()
         self._channels = model.in_channels
         self._model = model.model
-
-    @property
-    def model_file(self) -> str:
-        return self._model_file.name
 
     def run(self, input_tensor, device: str = "cuda"):
         if not isinstance(input_tensor, torch.Tensor):

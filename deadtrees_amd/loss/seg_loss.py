@@ -14,6 +14,7 @@ flag (`label_error`) that callers may check lazily.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -38,8 +39,15 @@ def gwdice_matrix(K: int, device) -> torch.Tensor:
     classes 0.5 apart), cut to K classes; its maximum is 1 so gwdl.py:74-79 does not rescale it."""
     if K not in (2, 3):
         raise NotImplementedError("GWDICE: the reference defines the distance matrix for 2 or 3 classes only")
-    m = torch.tensor([[0.0, 1.0, 1.0], [1.0, 0.0, 0.5], [1.0, 0.5, 0.0]], dtype=torch.float32)[:K, :K]
-    return m.contiguous().to(device)
+    key = (K, str(device))
+    m = _GW_CACHE.get(key)
+    if m is None:   # one host-to-device copy per (K, device), not one per step (and none inside a graph capture)
+        m = torch.tensor([[0.0, 1.0, 1.0], [1.0, 0.0, 0.5], [1.0, 0.5, 0.0]], dtype=torch.float32)[:K, :K]
+        m = _GW_CACHE[key] = m.contiguous().to(device)
+    return m
+
+
+_GW_CACHE: Dict = {}
 
 
 def loss_sums(logits: torch.Tensor, labels: torch.Tensor, distmap: Optional[torch.Tensor] = None,
@@ -74,102 +82,78 @@ def loss_sums(logits: torch.Tensor, labels: torch.Tensor, distmap: Optional[torc
     return acc[:B * K * NACC].view(B, K, NACC), probs, err
 
 
+_DICE_KINDS = {"GDICE": 0, "DICE": 1, "GWDICE": 2}
+_KIND_CODE = dict(_DICE_KINDS, NONE=3)
+
+
+def loss_forward(logits: torch.Tensor, labels: torch.Tensor, distmap: Optional[torch.Tensor], cfg: dict):
+    """reduction pass + device-side scalar algebra -> (parts fp32 [8] on the device, err flag, saved-for-backward).
+    parts[i] follows PART_KEYS; parts[7] (= total) is the scalar to differentiate.  No ATen arithmetic, no host sync."""
+    losses = cfg["losses"]
+    alpha = float(cfg.get("alpha", 1.0))
+    gamma = float(cfg.get("gamma", 2.0))
+    B, K, H, W = logits.shape
+    use_bd = ("BOUNDARY" in losses or "BOUNDARY-RAMPED" in losses) and distmap is not None
+    dev = logits.device
+    dice_kind = [n for n in losses if n in _DICE_KINDS]
+    if not dice_kind:
+        if not cfg.get("allow_no_dice"):
+            raise AssertionError("a dice term (GDICE, DICE or GWDICE) is mandatory")  # segmodel.py:143
+        dice_kind = ["NONE"]   # the stand-alone loss callables of loss/callables.py
+    dice_kind = dice_kind[-1]   # segmodel.py:113-127: a later entry replaces self.dice_loss
+    wass_m = gwdice_matrix(K, dev) if dice_kind == "GWDICE" else None
+    acc, _, err = loss_sums(logits, labels, distmap if use_bd else None, gamma, wass_m=wass_m)
+    # one fp32 workspace: parts[8] | coef[B*K*2] | wfocal[2] (+2 pad) | wbound[K -> 4] | wass_a[B] | wass_c[B]
+    o_coef, o_wf, o_wb, o_wa = 8, 8 + 2 * B * K, 8 + 2 * B * K + 4, 8 + 2 * B * K + 8
+    ws = torch.empty(o_wa + 2 * B, dtype=torch.float32, device=dev)
+    parts, coef, wf, wbound = ws[:8], ws[o_coef:o_wf], ws[o_wf:o_wf + 2], ws[o_wb:o_wb + K]
+    wass_a, wass_c = (ws[o_wa:o_wa + B], ws[o_wa + B:o_wa + 2 * B]) if wass_m is not None else (None, None)
+    c = _lib.LossCfg(_KIND_CODE[dice_kind], 1 if use_bd else 0, 1 if "FOCAL" in losses else 0,
+                     alpha if "BOUNDARY-RAMPED" in losses else 1.0, gamma)
+    _lib.check(_lib.load().dt_seg_loss_algebra(_p(acc), C.byref(c), B, K, H, W, _p(parts), _p(coef), _p(wf), _p(wbound),
+                                               _p(wass_a), _p(wass_c), _stream()), "dt_seg_loss_algebra")
+    saved = (logits, labels, distmap if use_bd else None, coef, wf, wbound if use_bd else None, wass_m, wass_c, wass_a)
+    return parts, err, saved
+
+
+def loss_backward(saved, gtotal: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d total / d logits (one elementwise pass); gtotal: optional 0-d fp32 device scalar (upstream gradient)"""
+    logits, labels, distmap, coef, wf, wbound, wass_m, wass_c, wass_a = saved
+    lib = _lib.load()
+    B, K, H, W = logits.shape
+    logits = logits.contiguous()
+    labels = labels.contiguous()
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    dl = torch.empty_like(logits)
+    gs = None
+    if gtotal is not None:
+        gs = gtotal.reshape(1)
+        if gs.dtype != torch.float32:
+            gs = gs.float()
+    posgrad = None
+    if wass_m is not None:
+        posgrad = torch.empty(H * W, dtype=torch.float32, device=logits.device)
+        _lib.check(lib.dt_gwdice_posgrad(_p(labels), _p(wass_a), _p(posgrad), B, H, W, _stream()),
+                   "dt_gwdice_posgrad")
+    _lib.check(lib.dt_seg_loss_bwd(_p(logits), _p(labels), _p(distmap), _p(coef), _p(wf), _p(wbound), _p(gs),
+                                   _p(wass_m), _p(wass_c), _p(posgrad), _p(dl), B, K, H, W, _stream()), "dt_seg_loss_bwd")
+    return dl
+
+
 class _SegLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, distmap, cfg):
-        losses = cfg["losses"]
-        alpha = float(cfg.get("alpha", 1.0))
-        gamma = float(cfg.get("gamma", 2.0))
-        B, K, H, W = logits.shape
-        use_bd = ("BOUNDARY" in losses or "BOUNDARY-RAMPED" in losses) and distmap is not None
-        dev = logits.device
-        dice_kind = [n for n in losses if n in ("GDICE", "DICE", "GWDICE")]
-        dice_kind = dice_kind[-1] if dice_kind else None   # segmodel.py:113-127: a later entry replaces self.dice_loss
-        wass_m = gwdice_matrix(K, dev) if dice_kind == "GWDICE" else None
-        acc, _, err = loss_sums(logits, labels, distmap if use_bd else None, gamma, wass_m=wass_m)
-        cnt, pt, ps, foc, ce, bd, tp, prs, ws, vs = (acc[..., i] for i in range(NACC))
-        wass_c = wass_a = None
-        coef_a = torch.zeros((B, K), dtype=torch.float64, device=dev)
-        coef_c = torch.zeros((B, K), dtype=torch.float64, device=dev)
-        parts: Dict[str, torch.Tensor] = {}
-        total = torch.zeros((), dtype=torch.float64, device=dev)
-        if dice_kind == "GWDICE":
-            # gwdl.py:110-138 (weighting_mode "default": alpha = 0 for background, 1 otherwise; mean over samples)
-            al = torch.ones(K, dtype=torch.float64, device=dev)
-            al[0:1].fill_(0.0)     # fill_: the scalar travels as a kernel argument (HIP-graph capturable)
-            gtp = (al[None, :] * vs).sum(1)      # sum_s alpha_i(s) * sum_j (1 - wass_j(s)): the reference's broadcast
-            ae = ws.sum(1)
-            den = 2.0 * gtp + ae + GW_EPS
-            parts["dice_loss"] = (1.0 - (2.0 * gtp + GW_EPS) / den).mean()
-            # d loss / d wass_j(s) = sum_i wass_a[i] * alpha_i(s) + wass_c[j]
-            wass_a = (2.0 * ae / (den * den) / B).float().contiguous()
-            wass_c = ((2.0 * gtp + GW_EPS) / (den * den) / B).float().contiguous()
-        elif dice_kind == "GDICE":
-            S = cnt.sum(0)
-            w = 1.0 / (S * S + 1e-9)
-            N = (w * pt.sum(0)).sum()
-            D = (w * (cnt.sum(0) + ps.sum(0))).sum()
-            parts["dice_loss"] = 1.0 - 2.0 * (N + 1e-9) / (D + 1e-9)
-            coef_a += (-2.0 * w / (D + 1e-9))[None, :]
-            coef_c += (2.0 * w * (N + 1e-9) / (D + 1e-9) ** 2)[None, :]
-        elif dice_kind == "DICE":
-            nfg = K - 1
-            I, U = pt[:, 1:], ps[:, 1:] + cnt[:, 1:]
-            parts["dice_loss"] = (1.0 - (2.0 * I + EPS) / (U + EPS)).mean()
-            coef_a[:, 1:] += -2.0 / (U + EPS) / (B * nfg)
-            coef_c[:, 1:] += (2.0 * I + EPS) / (U + EPS) ** 2 / (B * nfg)
-        else:
-            raise AssertionError("a dice term (GDICE, DICE or GWDICE) is mandatory")  # segmodel.py:143
-        total = total + parts["dice_loss"]
-        wbound = None
-        if use_bd:
-            nfg = K - 1
-            scale = 1.0 / (B * nfg * H * W)
-            parts["boundary_loss"] = bd[:, 1:].sum() * scale
-            wa = alpha if "BOUNDARY-RAMPED" in losses else 1.0
-            total = total + wa * parts["boundary_loss"]
-            wbound = torch.full((K,), wa * scale, dtype=torch.float32, device=dev)
-            wbound[0:1].fill_(0.0)
-        wf = torch.zeros(2, dtype=torch.float32, device=dev)
-        wf[1:2].fill_(gamma)
-        if "FOCAL" in losses:
-            M = cnt.sum() + EPS
-            parts["focal_loss"] = -foc.sum() / M
-            total = total + parts["focal_loss"]
-            wf[0:1].copy_((1.0 / M).float().reshape(1))
-        parts["ce_loss"] = -ce.sum() / (cnt.sum() + EPS)  # losses.py:187-196 (not part of total)
-        # smp Fscore (threshold 0.5, beta 1, eps 1e-7): ignore_channels=[0] and all channels
-        def fscore(sl):
-            tps, prsum, gts = tp[:, sl].sum(), prs[:, sl].sum(), cnt[:, sl].sum()
-            return (2.0 * tps + 1e-7) / (2.0 * tps + (gts - tps) + (prsum - tps) + 1e-7)
-        parts["dice"] = fscore(slice(1, None))
-        parts["dice_with_bg"] = fscore(slice(0, None))
-        parts["total_loss"] = total
-        coef = torch.stack([coef_a, coef_c], dim=-1).float().contiguous()
-        ctx.save_for_backward(logits, labels, distmap if use_bd else None, coef, wf, wbound, wass_m, wass_c, wass_a)
-        ctx.use_bd = use_bd
-        out_parts = torch.stack([parts.get(k, torch.zeros((), dtype=torch.float64, device=dev)).double() for k in
-                                 PART_KEYS]).float()
+        parts, err, saved = loss_forward(logits, labels, distmap, cfg)
+        ctx.save_for_backward(*saved)
+        out_parts = parts[:7]
+        total = parts[7]
         ctx.mark_non_differentiable(out_parts, err)
-        return total.float(), out_parts, err
+        return total, out_parts, err
 
     @staticmethod
     def backward(ctx, gtotal, _gparts, _gerr):
-        logits, labels, distmap, coef, wf, wbound, wass_m, wass_c, wass_a = ctx.saved_tensors
-        lib = _lib.load()
-        B, K, H, W = logits.shape
-        logits = logits.contiguous()
-        labels = labels.contiguous()
-        dl = torch.empty_like(logits)
-        gs = gtotal.reshape(1).float().contiguous()
-        posgrad = None
-        if wass_m is not None:
-            posgrad = torch.empty(H * W, dtype=torch.float32, device=logits.device)
-            _lib.check(lib.dt_gwdice_posgrad(_p(labels), _p(wass_a), _p(posgrad), B, H, W, _stream()),
-                       "dt_gwdice_posgrad")
-        _lib.check(lib.dt_seg_loss_bwd(_p(logits), _p(labels), _p(distmap), _p(coef), _p(wf), _p(wbound), _p(gs),
-                                       _p(wass_m), _p(wass_c), _p(posgrad), _p(dl), B, K, H, W, _stream()), "dt_seg_loss_bwd")
-        return dl, None, None, None
+        return loss_backward(ctx.saved_tensors, gtotal), None, None, None
 
 
 PART_KEYS = ("dice_loss", "boundary_loss", "focal_loss", "ce_loss", "dice", "dice_with_bg", "total_loss")

@@ -15,6 +15,7 @@ package is importable and a minimal stand-in otherwise (it is absent from this i
 """
 from __future__ import annotations
 
+import csv
 import json
 import logging
 import math
@@ -142,7 +143,10 @@ class SemSegment(_Base):
         assert any(n in ("GDICE", "GWDICE", "DICE") for n in self.loss_names)  # "we require GDICE!" (segmodel.py:143)
 
         self.stats = {"train": Counter(), "val": Counter(), "test": Counter()}
-        self.label_error = None  # device flag: labels outside [0,K) seen (class2one_hot's assert, lazily)
+        # device flags "labels outside [0,K) seen" (class2one_hot's assert, losses.py:129): collected per step
+        # without a host sync and checked when an epoch ends (`_check_labels`)
+        self.label_error = None
+        self._label_errors = []
         # device-side confusion counts [2,K,K] per stage (all pixels / lu == 1), instead of concatenating every
         # int64 mask of the epoch (reference validation_epoch_end / test_epoch_end, segmodel.py:291-407)
         self._cm = {}
@@ -153,43 +157,71 @@ class SemSegment(_Base):
         """blending parameter for boundary loss - ramps 0.01 -> 0.99 by epoch (segmodel.py:157-160)"""
         return min((self.current_epoch + 1) * self.initial_alpha, 0.99)
 
-    def calculate_loss(self, logits: Tensor, mask: Tensor, stage: str, distmap: Optional[Tensor] = None):
-        """compound loss of segmodel.py:169-200, from LOGITS and integer LABELS (fused softmax / one-hot).
-        Returns (loss, parts) and logs the reference's keys."""
+    @staticmethod
+    def _as_logits_labels(y_hat: Tensor, y: Tensor):
+        """The reference hands ``calculate_loss`` / ``log_metrics`` softmax PROBABILITIES and the int32 ONE-HOT target
+        (segmodel.py:215-218); the fused kernels want logits and integer labels.  A 4-D ``y`` marks a reference-style
+        call: log(p) is a valid logit vector for p (softmax(log p) == p), argmax recovers the labels."""
+        if y.dim() == y_hat.dim():
+            return torch.log(y_hat.float().clamp_min(1e-38)), y.argmax(dim=1)
+        return y_hat, y
+
+    def calculate_loss(self, y_hat: Tensor, y: Tensor, stage: str, distmap: Optional[Tensor] = None) -> Tensor:
+        """compound loss of segmodel.py:169-200 -> loss tensor; logs the reference's ``{stage}/...`` keys.
+        Accepts the reference's arguments (probabilities, one-hot) and, natively, (logits, integer labels); the
+        per-term values of the last call stay in ``self.last_parts`` (metrics included: no second pass)."""
+        logits, mask = self._as_logits_labels(y_hat, y)
         use_dist = distmap if any(n.startswith("BOUNDARY") for n in self.loss_names) else None
         if use_dist is None and any(n.startswith("BOUNDARY") for n in self.loss_names):
             use_dist = distmaps_on_device(mask, logits.shape[1])   # loader attached none: HIP EDT on the labels
         loss, parts, err = seg_loss(logits, mask, use_dist, self.loss_names, alpha=self.alpha)
         self.label_error = err
+        self._label_errors.append(err)
+        self.last_parts = parts
         self.log(f"{stage}/dice_loss", parts["dice_loss"], on_step=False, on_epoch=True)
         if use_dist is not None:
             self.log(f"{stage}/boundary_loss", parts["boundary_loss"], on_step=False, on_epoch=True)
         if "FOCAL" in self.loss_names:
             self.log(f"{stage}/focal_loss", parts["focal_loss"], on_step=False, on_epoch=True)
         self.log(f"{stage}/total_loss", loss, on_step=False, on_epoch=True)
-        return loss, parts
+        return loss
 
-    def log_metrics(self, parts, *, stage: str):
+    def log_metrics(self, y_hat, y: Optional[Tensor] = None, *, stage: str):
+        """segmodel.py:202-208.  ``log_metrics(y_hat, y, stage=...)`` like the reference (probabilities + one-hot, or
+        logits + labels), or ``log_metrics(parts, stage=...)`` with the sums a ``calculate_loss`` call already made."""
+        if isinstance(y_hat, dict):
+            parts = y_hat
+        else:
+            logits, mask = self._as_logits_labels(y_hat, y)
+            _, parts, err = seg_loss(logits.detach(), mask, None, [n for n in self.loss_names if not n.startswith("BOUNDARY")])
+            self._label_errors.append(err)
         self.log(f"{stage}/dice", parts["dice"], on_step=False, on_epoch=True)
         self.log(f"{stage}/dice_with_bg", parts["dice_with_bg"], on_step=False, on_epoch=True)
+
+    def _check_labels(self):
+        """the lazily evaluated assert of class2one_hot (losses.py:129): one host sync per epoch instead of two per step"""
+        errs, self._label_errors = self._label_errors, []
+        if errs and int(torch.stack([e.reshape(()) for e in errs]).max()) != 0:
+            raise AssertionError(f"labels outside [0, {len(self.classes)}) were seen this epoch (class2one_hot)")
 
     # ------------------------------------------------------------------ steps
     def training_step(self, batch, batch_idx):
         img, mask, distmap, _, stats = create_combined_batch(batch)
         logits = self.model(img)
-        loss, parts = self.calculate_loss(logits, mask, "train", distmap=distmap)
+        loss = self.calculate_loss(logits, mask, "train", distmap=distmap)
         if torch.isnan(loss) or torch.isinf(loss):   # the one host sync per step the reference also has
             log.warning("Train loss is NaN! What is going on?")
             return None
-        self.log_metrics(parts, stage="train")
+        self.log_metrics(self.last_parts, stage="train")
         self.stats["train"].update([x["file"] for x in stats])
         return loss
 
     def validation_step(self, batch, batch_idx):
         img, mask, distmap, lu, stats = create_combined_batch(batch)
-        logits = self.model(img)
-        loss, parts = self.calculate_loss(logits, mask, stage="val", distmap=distmap)
-        self.log_metrics(parts, stage="val")
+        with torch.no_grad():       # Lightning evaluates under no_grad; the stand-in base class must too, or a
+            logits = self.model(img)    # grad-enabled forward would keep a second set of saved activations alive
+            loss = self.calculate_loss(logits, mask, stage="val", distmap=distmap)
+        self.log_metrics(self.last_parts, stage="val")
         self.stats["val"].update([x["file"] for x in stats])
         pred = logits.argmax(dim=1)
         self._accumulate_cm("val", pred, mask, lu)
@@ -197,10 +229,9 @@ class SemSegment(_Base):
 
     def test_step(self, batch: Tuple[Tensor], batch_idx) -> Dict[str, Any]:
         img, mask, _, lu, stats = batch
-        logits = self.model(img)
-        _, parts, err = seg_loss(logits, mask, None, [n for n in self.loss_names if not n.startswith("BOUNDARY")])
-        self.label_error = err
-        self.log_metrics(parts, stage="test")
+        with torch.no_grad():
+            logits = self.model(img)
+            self.log_metrics(logits, mask, stage="test")
         self.stats["test"].update([x["file"] for x in stats])
         pred = logits.argmax(dim=1)
         self._accumulate_cm("test", pred, mask, lu)
@@ -224,10 +255,22 @@ class SemSegment(_Base):
         return out
 
     def validation_epoch_end(self, outputs=None):
+        self._check_labels()
         return self.confusion_matrices("val")
 
     def test_epoch_end(self, outputs=None):
+        self._check_labels()
         return self.confusion_matrices("test")
+
+    def teardown(self, stage=None) -> None:
+        """reference segmodel.py:409-418: per-file sample counts of the run -> train_stats.csv / val_stats.csv in the
+        working directory (columns filename,count — what ``DataFrame.to_csv(index=False)`` writes)"""
+        for name in ("train", "val"):
+            log.debug(f"len(stats_{name}): {len(self.stats[name])}")
+            with open(f"{name}_stats.csv", "w", newline="") as f:
+                w = csv.writer(f, lineterminator="\n")
+                w.writerow(["filename", "count"])
+                w.writerows(dict(self.stats[name]).items())
 
     def configure_optimizers(self):
         opt = torch.optim.Adam(self.parameters(), lr=self.hparams["training"]["learning_rate"])
@@ -244,11 +287,10 @@ class SemSegment(_Base):
 
     @classmethod
     def load_from_checkpoint(cls, path, map_location="cpu", **_):
-        if HAVE_LIGHTNING:  # pragma: no cover
-            try:
-                return super().load_from_checkpoint(path, map_location=map_location)
-            except Exception:  # noqa: BLE001 - fall through to the plain format
-                pass
+        """Never unpickles arbitrary objects, with or without Lightning installed (Lightning's own
+        ``load_from_checkpoint`` is a full-pickle ``torch.load`` that imports and runs whatever the file names): first
+        the ``weights_only`` loader (this module's ``save_checkpoint`` format), then the restricted reader of
+        utils/ckpt.py for the reference's Lightning ``.ckpt`` files."""
         try:
             ck = torch.load(str(path), map_location=map_location, weights_only=True)
         except Exception:  # noqa: BLE001 - pickled omegaconf / Lightning objects: weights_only refuses them
@@ -273,3 +315,17 @@ class SemSegment(_Base):
 def cosine_lr(base_lr: float, epoch: int, t_max: int, eta_min: float = 0.0) -> float:
     """closed form of torch CosineAnnealingLR stepped once per epoch (segmodel.py:426-428)"""
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2
+
+
+def initialize_weights(m):
+    """reference segmodel.py:432-438: zero biases, Kaiming-normal conv/linear weights, recursively.  ``UNetHIP`` keeps
+    its parameters in one flat buffer and re-draws them itself (same distribution: fan_in, gain sqrt 2)."""
+    if isinstance(m, UNetHIP):
+        m.reset_parameters()
+        return
+    if getattr(m, "bias", None) is not None:
+        torch.nn.init.constant_(m.bias, 0)
+    if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+        torch.nn.init.kaiming_normal_(m.weight)
+    for c in m.children():
+        initialize_weights(c)

@@ -59,13 +59,21 @@ class UNetEngine:
         # side-stream weight gradients: measured SLOWER on MI355X (485 vs 528 tiles/s fp32, 1505 vs 1566 bf16): the
         # co-resident wgrad / dgrad workgroups halve each other's occupancy and share the matrix pipe — off by default
         self.overlap_wgrad = False
+        self._bwd_training = True
         # BatchNorm-backward reduction of a block-output layer inside the fp32 gradient-JOIN epilogue: measured slower
         # than the separate pass (526 vs 530 tiles/s, same box: 48 extra loads per lane in the read-modify-write
         # epilogue); the bf16 path keeps it (its join epilogue is LDS-staged, +0.5 %).  Kernel support stays tested.
         self.fuse_join_fp32 = False
         self._fuse_bn = not os.environ.get("DT_NO_BN_FUSE")   # A/B switch for the plain fused reductions
+        # when a dict: the bf16 training pass stores a copy of every intermediate tensor it produces under the
+        # names of oracle/unet_bf16_ref.py (teacher-forced parity test); None in production
+        self.trace: Optional[dict] = None
 
     # ------------------------------------------------------------------ helpers
+    def _tr(self, name: str, t: Optional[torch.Tensor]):
+        if self.trace is not None and t is not None:
+            self.trace[name] = t.clone()
+
     def _buf(self, name: str, numel: int, dtype=torch.float32, device=None) -> torch.Tensor:
         t = self._ws.get(name)
         if t is None or t.numel() < numel or t.device != device:
@@ -113,7 +121,8 @@ class UNetEngine:
         nb = self.spec.n_bn_channels
         return (bnws[2 * nb + c.bn_off: 2 * nb + c.bn_off + c.cout], bnws[3 * nb + c.bn_off: 3 * nb + c.bn_off + c.cout])
 
-    def _conv_bn(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, training, in_ss=None):
+    def _conv_bn(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, training, in_ss=None,
+                 save_stats=False):
         """y = conv(x); BN statistics -> per-channel scale/shift in bnws.  Returns y, (Ho, Wo).
         in_ss: (scale, shift) of the layer that produced src0 when src0 is a RAW conv output whose
         BatchNorm-apply + ReLU is fused into this conv's LDS staging (virtual activation)."""
@@ -148,6 +157,9 @@ class UNetEngine:
             self._conv(desc, src0, src1, w, y, None, None, in_ss)
             _lib.check(self.lib.dt_bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), BN_EPS, c.cout,
                                                   _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
+            if save_stats:   # a backward pass may follow (frozen-BatchNorm fine-tuning): xhat uses the running stats
+                _lib.check(self.lib.dt_bn_eval_stats(_p(rmean), _p(rvar), BN_EPS, c.cout, _p(mean), _p(invstd),
+                                                     _stream()), "dt_bn_eval_stats")
         return y, Ho, Wo, (scale, shift)
 
     def _bn_act(self, y, ss, res=None, res_ss=None, relu=True, out=None):
@@ -188,7 +200,7 @@ class UNetEngine:
                 sv.d[key] = kw
 
         # ---- stem
-        y, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, training)
+        y, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, training, save_stats=save)
         f1 = self._bn_act(y, ss)
         keep("stem", x=x, y=y, z=f1, Hin=H, Win=W)
         hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
@@ -202,12 +214,14 @@ class UNetEngine:
         for li, blocks in enumerate(sp.layers):
             for bi, blk in enumerate(blocks):
                 xin = cur
-                y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw, training)
+                y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw, training,
+                                                        save_stats=save)
                 # z1 = relu(bn1(y1)) is virtual: conv2 applies it while staging y1
                 y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
-                                                in_ss=ss1)
+                                                in_ss=ss1, save_stats=save)
                 if blk.down is not None:
-                    yd, _, _, ssd = self._conv_bn(blk.down, params, bnstate, bnws, xin, None, 0, B, ch, cw, training)
+                    yd, _, _, ssd = self._conv_bn(blk.down, params, bnstate, bnws, xin, None, 0, B, ch, cw, training,
+                                                  save_stats=save)
                     out = self._bn_act(y2, ss2, res=yd, res_ss=ssd)
                 else:
                     yd = None
@@ -223,9 +237,9 @@ class UNetEngine:
             skip = skips[i]
             Hin, Win = 2 * dh, 2 * dw
             y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training,
-                                            in_ss=d_ss)
+                                            in_ss=d_ss, save_stats=save)
             y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
-                                            in_ss=ss1)
+                                            in_ss=ss1, save_stats=save)
             if i == len(sp.decoder) - 1:
                 z2 = self._bn_act(y2, ss2)      # the head kernel reads a materialised activation
                 nxt, nxt_ss = z2, None
@@ -251,6 +265,7 @@ class UNetEngine:
         keep("head", x=d, H=dh, W=dw)
         if save:
             sv.d["B"] = B
+            sv.d["training"] = bool(training)
             self.saved = sv
         return logits, (am64 if am64 is not None else am8)
 
@@ -529,6 +544,7 @@ class UNetEngine:
         amax = torch.empty((B, hp, wp, 64), dtype=torch.uint8, device=dev)
         _lib.check(lib.dt_maxpool3x3s2_bf16_amax(_p(f1), _p(pool), _p(amax), B, h, w_, 64, st), "dt_maxpool3x3s2_bf16_amax")
         sv.d["pool"] = dict(amax=amax, H=h, W=w_)
+        self._tr("pool", pool)
         feats = [f1]
         cur, ch, cw = pool, hp, wp
         for li, blocks in enumerate(sp.layers):
@@ -570,10 +586,14 @@ class UNetEngine:
         self.saved = sv
         return logits
 
-    def backward_bf16(self, dlogits: torch.Tensor, params: torch.Tensor, grads: torch.Tensor):
+    def backward_bf16(self, dlogits: torch.Tensor, params: torch.Tensor, grads: torch.Tensor,
+                      saved: Optional[_Saved] = None):
         """reverse pass of forward_bf16_train: bf16 activation gradients, fp32 parameter gradients"""
         sp, lib = self.spec, self.lib
-        S = self.saved.d
+        sv = saved if saved is not None else self.saved
+        if sv is None:
+            raise RuntimeError("backward called without a saved forward (was another forward run in between?)")
+        S = sv.d
         B, bnws = S["B"], S["bnws"]
         dev, st, bf = dlogits.device, _stream(), torch.bfloat16
         wbd = self._bf16_weights(params, dgrad=True)
@@ -652,6 +672,7 @@ class UNetEngine:
                    "dt_head_bwd_bf16")
         _lib.check(lib.dt_head_bwd_finalize(_p(red), P, _p(grads[hd.w_off:hd.w_off + hd.w_size]),
                                             _p(grads[hd.b_off:hd.b_off + K]), hd.cin, K, st), "dt_head_bwd_finalize")
+        self._tr("head.g", g)
 
         skip_grads = [None] * 5
         g_red = None
@@ -659,11 +680,14 @@ class UNetEngine:
             blk, d = sp.decoder[i], S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
             dy2 = bn_bwd(blk.conv2, g, d["z2"], d["y2"], virtual_act=d["z2"] is None, reduced=g_red)
+            self._tr(f"D{i}.dy2", dy2)
             wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty(d["y1"].shape, dtype=bf, device=dev)
             red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, d["y1"])
             del dy2
+            self._tr(f"D{i}.dz1", dz1)
             dy1 = bn_bwd(blk.conv1, dz1, None, d["y1"], virtual_act=True, reduced=red1)
+            self._tr(f"D{i}.dy1", dy1)
             del dz1
             x_ss = self._ss(sp.decoder[i - 1].conv2, bnws) if d["x_virtual"] else None
             wgrad(blk.conv1, d["x"], d["skip"], 1, Hh, Ww, dy1, in_ss=x_ss)
@@ -673,8 +697,10 @@ class UNetEngine:
                 dskip = torch.empty(d["skip"].shape, dtype=bf, device=dev)
                 dgrad(blk.conv1, dy1, Hh, Ww, dup, dskip, split=cx)
                 skip_grads[3 - i] = dskip
+                self._tr(f"D{i}.dskip", dskip)
             else:
                 dgrad(blk.conv1, dy1, Hh, Ww, dup)
+            self._tr(f"D{i}.dup", dup)
             del dy1
             g = torch.empty(d["x"].shape, dtype=bf, device=dev)
             g_red = None
@@ -693,6 +719,7 @@ class UNetEngine:
                 _lib.check(lib.dt_upsample2x_bwd_bf16(_p(dup), _p(g), B, Hh // 2, Ww // 2, cx, st),
                            "dt_upsample2x_bwd_bf16")
             del dup
+            self._tr(f"D{i}.g", g)
             S[f"D{i}"] = None
         if self.grad_hook:
             self._join_side()
@@ -712,16 +739,22 @@ class UNetEngine:
                     dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gin, dres_acc=gin_has, reduced=g_red)
                     gin_has = True
                     dyd = None
+                    self._tr(f"L{li}B{bi}.gres", gin)
                 else:
                     gd = torch.empty(r["out"].shape, dtype=bf, device=dev)
                     dy2 = bn_bwd(blk.conv2, g, r["out"], r["y2"], dres=gd, reduced=g_red)
                     dyd = bn_bwd(blk.down, gd, None, r["yd"])
+                    self._tr(f"L{li}B{bi}.gres", gd)
+                    self._tr(f"L{li}B{bi}.dyd", dyd)
                     del gd
+                self._tr(f"L{li}B{bi}.dy2", dy2)
                 wgrad(blk.conv2, r["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
                 dz1 = torch.empty(r["y1"].shape, dtype=bf, device=dev)
                 red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, r["y1"])
                 del dy2
+                self._tr(f"L{li}B{bi}.dz1", dz1)
                 dy1 = bn_bwd(blk.conv1, dz1, None, r["y1"], virtual_act=True, reduced=red1)
+                self._tr(f"L{li}B{bi}.dy1", dy1)
                 del dz1
                 wgrad(blk.conv1, r["x"], None, 0, Hin, Win, dy1)
                 g_red = None
@@ -733,10 +766,12 @@ class UNetEngine:
                     dgrad(blk.conv1, dy1, Hin, Win, gin, acc=gin_has)
                 gin_has = True
                 del dy1
+                self._tr(f"L{li}B{bi}.gin1", gin)
                 if dyd is not None:
                     wgrad(blk.down, r["x"], None, 0, Hin, Win, dyd)
                     dgrad(blk.down, dyd, Hin, Win, gin, acc=True)
                     del dyd
+                    self._tr(f"L{li}B{bi}.gin", gin)
                 g = gin
                 S[f"L{li}B{bi}"] = None
             if li > 0 and self.grad_hook:
@@ -747,7 +782,9 @@ class UNetEngine:
         gf1 = skip_grads[0]
         _lib.check(lib.dt_maxpool3x3s2_bwd_bf16(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
                    "dt_maxpool3x3s2_bwd_bf16")
+        self._tr("gf1", gf1)
         dy = bn_bwd(sp.stem, gf1, stem["z"], stem["y"])
+        self._tr("stem.dy", dy)
         stc = sp.stem
         if stem.get("s2d") is not None:
             # space-to-depth form on the bf16 MFMA kernels: dW over 16 taps x 16 channels, gathered back to 7x7
@@ -797,10 +834,12 @@ class UNetEngine:
             _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc), _p(ash),
                                                  _p(red), n_pix, Cc, st), "dt_bn_bwd_reduce")
         dy = torch.empty_like(y)
-        _lib.check(self.lib.dt_bn_bwd_apply(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(asc),
-                                            _p(ash), _p(red), P,
-                                            _p(grads[c.g_off:c.g_off + Cc]), _p(grads[c.b_off:c.b_off + Cc]),
-                                            _p(dy), _p(dres), 1 if dres_acc else 0, n_pix, Cc, st),
+        # eval-mode (frozen) BatchNorm: y*scale+shift with constant statistics -> dy = g*gamma*invstd, no mean terms
+        fn = self.lib.dt_bn_bwd_apply if self._bwd_training else self.lib.dt_bn_bwd_apply_frozen
+        _lib.check(fn(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(asc),
+                      _p(ash), _p(red), P,
+                      _p(grads[c.g_off:c.g_off + Cc]), _p(grads[c.b_off:c.b_off + Cc]),
+                      _p(dy), _p(dres), 1 if dres_acc else 0, n_pix, Cc, st),
                    "dt_bn_bwd_apply")
         return dy
 
@@ -865,14 +904,16 @@ class UNetEngine:
         self._conv(desc, dy, None, wd, out0, out1, None)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dlogits: torch.Tensor, params: torch.Tensor, grads: torch.Tensor):
+    def backward(self, dlogits: torch.Tensor, params: torch.Tensor, grads: torch.Tensor, saved: Optional[_Saved] = None):
         """Hand-scheduled reverse pass.  Writes every parameter gradient into ``grads`` (flat, same layout
-        as ``params``) and calls ``grad_hook(name, lo, hi)`` as each bucket of the flat buffer completes."""
+        as ``params``) and calls ``grad_hook(name, lo, hi)`` as each bucket of the flat buffer completes.
+        ``saved``: the activations of the forward pass this gradient belongs to (default: the engine's last one)."""
         sp, lib = self.spec, self.lib
-        sv = self.saved
+        sv = saved if saved is not None else self.saved
         if sv is None:
-            raise RuntimeError("backward called without a saved training forward")
+            raise RuntimeError("backward called without a saved forward (was another forward run in between?)")
         S = sv.d
+        self._bwd_training = bool(S.get("training", True))
         B = S["B"]
         bnws = S["bnws"]
         dev = dlogits.device
@@ -1022,10 +1063,14 @@ class UNetEngine:
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, flat, module):
+        eng = module.engine
         if module.precision == "bf16" and module.training:
-            logits = module.engine.forward_bf16_train(x, flat.detach(), module.bn_state)
+            logits = eng.forward_bf16_train(x, flat.detach(), module.bn_state)
         else:
-            logits, _ = module.engine.forward(x, flat.detach(), module.bn_state, module.training, save=True)
+            logits, _ = eng.forward(x, flat.detach(), module.bn_state, module.training, save=True)
+        # the activations belong to THIS autograd node, not to the engine: another grad-enabled forward (a validation
+        # step, a second loss term) between this forward and its backward must not replace them
+        ctx.saved_acts, eng.saved = eng.saved, None
         ctx.module = module
         module._bn_tracked_inc()
         return logits
@@ -1034,10 +1079,13 @@ class _UNetFunction(torch.autograd.Function):
     def backward(ctx, dlogits):
         m = ctx.module
         grads = m._grad_buffer()
-        if m.engine.saved is not None and m.engine.saved.d.get("bf16"):
-            m.engine.backward_bf16(dlogits, m.flat_params.detach(), grads)
+        sv, ctx.saved_acts = ctx.saved_acts, None
+        if sv is None:
+            raise RuntimeError("UNetHIP: backward through the same forward twice (activations are freed after use)")
+        if sv.d.get("bf16"):
+            m.engine.backward_bf16(dlogits, m.flat_params.detach(), grads, saved=sv)
         else:
-            m.engine.backward(dlogits, m.flat_params.detach(), grads)
+            m.engine.backward(dlogits, m.flat_params.detach(), grads, saved=sv)
         # a trainer that consumes the flat buffer directly (HipTrainer) opts out of autograd's copy into .grad
         return None, (grads if m.deliver_grad_to_autograd else None), None
 

@@ -288,8 +288,18 @@ def conv2d_wgrad_bf16(src0, dy, k, stride, pad, src1=None, mode0=0, in_scale=Non
 def confusion_matrix(pred, target, lu=None, K=2, counts=None):
     """counts int64 [2,K,K] (+=): [0] all pixels, [1] pixels with lu == 1; rows target, cols prediction."""
     _gpu(pred, target, lu)
+    # the kernel reads target / lu as int64 for pred.numel() elements: anything else would run past the allocation
+    if target.numel() != pred.numel() or (lu is not None and lu.numel() != pred.numel()):
+        raise RuntimeError(f"confusion_matrix: prediction {tuple(pred.shape)}, target {tuple(target.shape)}" +
+                           (f", lu {tuple(lu.shape)}" if lu is not None else "") + " must have the same number of pixels")
+    if target.dtype != torch.int64:
+        target = target.long()
+    if lu is not None and lu.dtype != torch.int64:
+        lu = lu.long()
     if counts is None:
         counts = torch.zeros((2, K, K), dtype=torch.int64, device=pred.device)
+    elif counts.dtype != torch.int64 or tuple(counts.shape) != (2, K, K) or counts.device != pred.device:
+        raise RuntimeError(f"confusion_matrix: counts must be int64 [2,{K},{K}] on {pred.device}")
     err = torch.zeros(1, dtype=torch.int32, device=pred.device)
     pred = pred.contiguous()
     p64 = pred if pred.dtype == torch.int64 else None
@@ -542,7 +552,13 @@ def signed_distmap(labels: torch.Tensor, K: int):
 
 class FlatAdam:
     """clip_grad_norm_(max_norm) + torch.optim.Adam on one flat buffer, two fused HIP passes
-    (reference: configs/trainer/default.yaml:18 + segmodel.py:420-425)."""
+    (reference: configs/trainer/default.yaml:18 + segmodel.py:420-425).
+
+    Every per-step scalar lives on the device: the step count ``t_dev`` (advanced by ``dt_adam_advance`` only when the
+    step is not skipped — Lightning does not call ``optimizer.step`` when ``training_step`` returns None, so the bias
+    correction must not move either), the learning rate ``lr_dev`` (refreshed by a stream-ordered fill when ``lr``
+    changes) and the bias corrections.  The launch sequence is therefore identical for every step: no ATen algebra,
+    no host synchronisation, capturable in a HIP graph."""
 
     def __init__(self, params: torch.Tensor, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, max_norm: float = 0.5):
         _gpu(params)
@@ -550,35 +566,54 @@ class FlatAdam:
         self.m = torch.zeros_like(params)
         self.v = torch.zeros_like(params)
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
-        self.t = 0
+        self.t = 0          # host mirror: number of step() calls (skipped steps included; the device count is t_dev)
         lib = _lib.load()
+        dev = params.device
         self.rows = lib.dt_sumsq_rows(params.numel())
-        self.partial = torch.empty(self.rows, dtype=torch.float64, device=params.device)
-        self.norm = torch.zeros(1, dtype=torch.float32, device=params.device)
-        self.coef = torch.ones(1, dtype=torch.float32, device=params.device)
+        self.partial = torch.empty(self.rows, dtype=torch.float64, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+        self.t_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float64, device=dev)
+        self._lr_on_dev = float(lr)
+        self.hyper = torch.ones(3, dtype=torch.float32, device=dev)
+        self.skip = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def hyper_values(self, lr: Optional[float] = None):
-        """(lr, 1 - beta1^t, 1 - beta2^t) for the CURRENT step count: what `dt_adam_step_dev` reads from the device"""
-        b1, b2 = self.betas
-        return [float(self.lr if lr is None else lr), 1.0 - b1 ** self.t, 1.0 - b2 ** self.t]
+    def sync_lr(self):
+        """push a changed learning rate to the device (stream-ordered fill: the value travels as a kernel argument).
+        Call OUTSIDE graph capture / before a replay."""
+        if self._lr_on_dev != float(self.lr):
+            self.lr_dev.fill_(float(self.lr))
+            self._lr_on_dev = float(self.lr)
+
+    def skip_from_loss(self, loss: torch.Tensor) -> torch.Tensor:
+        """device flag int32[1] = loss is NaN/Inf (segmodel.py:220-222); `loss` fp32 device scalar"""
+        _gpu(loss)
+        if loss.dtype != torch.float32:
+            loss = loss.float()
+        _lib.check(_lib.load().dt_skip_from_loss(_p(loss), _p(self.skip), _st()), "dt_skip_from_loss")
+        return self.skip
+
+    def steps_applied(self) -> int:
+        """optimiser steps that were not skipped (host sync)"""
+        return int(self.t_dev.item())
 
     def step(self, grads: torch.Tensor, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None,
-             lr: Optional[float] = None, hyper: Optional[torch.Tensor] = None):
-        """`hyper` (device fp32 [3], see hyper_values) makes the launch sequence independent of the step count, as
-        HIP-graph capture needs; the caller then advances `self.t` and refreshes `hyper` before every replay."""
+             lr: Optional[float] = None, capturing: bool = False):
         lib = _lib.load()
+        if lr is not None:
+            self.lr = lr
+        if not capturing:
+            self.sync_lr()
         n = self.p.numel()
         st = _st()
         _lib.check(lib.dt_sumsq(_p(grads), n, _p(self.partial), st), "dt_sumsq")
         _lib.check(lib.dt_clip_coef(_p(self.partial), self.rows, float(self.max_norm or 0.0), float(grad_scale),
                                     _p(self.norm), _p(self.coef), st), "dt_clip_coef")
         b1, b2 = self.betas
-        if hyper is not None:
-            _lib.check(lib.dt_adam_step_dev(_p(self.p), _p(grads), _p(self.m), _p(self.v), n, _p(hyper), b1, b2,
-                                            self.eps, _p(self.coef), _p(skip_flag), st), "dt_adam_step_dev")
-            return self.norm
+        _lib.check(lib.dt_adam_advance(_p(self.t_dev), _p(skip_flag), _p(self.lr_dev), b1, b2, _p(self.hyper), st),
+                   "dt_adam_advance")
+        _lib.check(lib.dt_adam_step_dev(_p(self.p), _p(grads), _p(self.m), _p(self.v), n, _p(self.hyper), b1, b2,
+                                        self.eps, _p(self.coef), _p(skip_flag), st), "dt_adam_step_dev")
         self.t += 1
-        _lib.check(lib.dt_adam_step(_p(self.p), _p(grads), _p(self.m), _p(self.v), n,
-                                    float(self.lr if lr is None else lr), b1, b2, self.eps, 1.0 - b1 ** self.t,
-                                    1.0 - b2 ** self.t, _p(self.coef), _p(skip_flag), st), "dt_adam_step")
         return self.norm

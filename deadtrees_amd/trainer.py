@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from .data.distmap import distmaps_on_device
-from .loss.seg_loss import seg_loss
+from .loss.seg_loss import PART_KEYS, loss_backward, loss_forward
 from .network.unet import UNetHIP
 from .ops import FlatAdam
 
@@ -102,56 +102,69 @@ class HipTrainer:
         g["mask"].copy_(mask)
         if distmap is not None:
             g["distmap"].copy_(distmap)
-        self.opt.t += 1                      # host mirror of the device step counter g["t"]
-        if g["lr_value"] != self.opt.lr:     # stream-ordered fill (value travels as a kernel argument): no host
-            g["lr"].fill_(self.opt.lr)       # buffer the run-ahead host could overwrite before the GPU reads it
-            g["lr_value"] = self.opt.lr
+        self.opt.sync_lr()                   # a changed learning rate reaches the replay through lr_dev
+        self.opt.t += 1                      # host mirror; the authoritative count is the device's t_dev
         g["graph"].replay()
         self.model.engine.mark_weights_changed()
+        self.model.num_batches_tracked += 1  # module bookkeeping outside the graph (smp state_dict key)
         self.last = g["last"]
         return g["last"]["loss"]
 
     def _capture(self, g, img, mask, distmap, alpha):
-        m, eng = self.model, self.model.engine
-        dev = img.device
+        eng = self.model.engine
         g["img"], g["mask"] = img.clone(), mask.clone()
         g["distmap"] = None if distmap is None else distmap.clone()
-        # Adam's per-step scalars live on the device: step counter, learning rate, and (lr, 1-b1^t, 1-b2^t)
-        g["t"] = torch.tensor([float(self.opt.t)], dtype=torch.float64, device=dev)
-        g["lr"] = torch.tensor([float(self.opt.lr)], dtype=torch.float64, device=dev)
-        g["lr_value"] = self.opt.lr
-        g["hyper"] = torch.ones(3, dtype=torch.float32, device=dev)
+        self.opt.sync_lr()
+        t_host = self.opt.t
         eager_ws, eng._ws = eng._ws, {}       # workspaces of the captured step live (and stay) in the graph's pool
         graph = torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
             with torch.cuda.graph(graph):
-                b1, b2 = self.opt.betas
-                g["t"].add_(1.0)
-                g["hyper"].copy_(torch.cat([g["lr"], 1.0 - torch.pow(b1, g["t"]), 1.0 - torch.pow(b2, g["t"])]))
-                self._eager_step(g["img"], g["mask"], g["distmap"], alpha, hyper=g["hyper"])
+                self._eager_step(g["img"], g["mask"], g["distmap"], alpha, capturing=True)
         finally:
             g["ws"], eng._ws = eng._ws, eager_ws
+        self.opt.t = t_host                   # capture launched nothing: the step count has not moved
         g["graph"], g["last"] = graph, self.last
 
-    def _eager_step(self, img, mask, distmap, alpha, hyper=None):
-        m = self.model
+    def _eager_step(self, img, mask, distmap, alpha, capturing: bool = False):
+        """forward -> fused loss -> hand-scheduled backward -> (all-reduce) -> clip + Adam, straight on the C ABI:
+        no autograd graph, no ATen arithmetic; every launch is the same for every step (HIP-graph capturable)."""
+        m, eng, opt = self.model, self.model.engine, self.opt
         m.train()
-        m.flat_params.grad = None
-        logits = m(img)
-        if distmap is None and any(n.startswith("BOUNDARY") for n in self.losses):
-            distmap = distmaps_on_device(mask, logits.shape[1])
-        loss, parts, err = seg_loss(logits, mask, distmap, self.losses, alpha=alpha)
-        loss.backward()
-        if self.reducer:
-            self.reducer.wait()
-        # non-finite loss -> skip the update (reference segmodel.py:220-222 returns None)
-        skip = (~torch.isfinite(loss.detach())).to(torch.int32).reshape(1)
-        norm = self.opt.step(m._grad_buffer(), grad_scale=1.0 / self.world, skip_flag=skip, hyper=hyper)
-        m.engine.mark_weights_changed()   # the fused optimiser wrote the flat buffer behind torch's version counter
-        m.flat_params.grad = None
-        self.last = {"loss": loss.detach(), "parts": parts, "grad_norm": norm, "label_error": err, "skipped": skip}
-        return loss.detach()
+        m._require_gpu(img)
+        params = m.flat_params.detach()
+        grads = m._grad_buffer()
+        with torch.no_grad():
+            x = img if img.dtype == torch.float32 else img.float()
+            if m.precision == "bf16":
+                logits = eng.forward_bf16_train(x, params, m.bn_state)
+            else:
+                logits, _ = eng.forward(x, params, m.bn_state, True, save=True)
+            if not capturing:
+                m.num_batches_tracked += 1
+            if distmap is None and any(n.startswith("BOUNDARY") for n in self.losses):
+                distmap = distmaps_on_device(mask, logits.shape[1])
+            parts, err, saved = loss_forward(logits, mask, distmap, {"losses": self.losses, "alpha": alpha})
+            dl = loss_backward(saved)
+            if m.precision == "bf16":
+                eng.backward_bf16(dl, params, grads)
+            else:
+                eng.backward(dl, params, grads)
+            if self.reducer:
+                self.reducer.wait()
+            # non-finite loss -> skip the update (reference segmodel.py:220-222 returns None).  The decision must be
+            # GLOBAL: the gradient buckets are already summed over the replicas, so one rank's NaN poisons everyone's
+            # update — all ranks skip together (one 4-byte MAX all-reduce on the same group)
+            loss = parts[7]
+            skip = opt.skip_from_loss(loss)
+            if self.reducer and self.world > 1:
+                self.reducer.dist.all_reduce(skip, op=self.reducer.dist.ReduceOp.MAX, group=self.reducer.group)
+            norm = opt.step(grads, grad_scale=1.0 / self.world, skip_flag=skip, capturing=capturing)
+        eng.mark_weights_changed()   # the fused optimiser wrote the flat buffer behind torch's version counter
+        self.last = {"loss": loss, "parts": {k: parts[i] for i, k in enumerate(PART_KEYS)}, "grad_norm": norm,
+                     "label_error": err, "skipped": skip}
+        return loss
 
 
 def fit(trainer: HipTrainer, loader, epochs: int, base_lr: float = 3e-4, t_max: int = 10, to_device=None,

@@ -67,7 +67,8 @@ def _rebuild_tensor_v2(storage, storage_offset, size, stride, requires_grad=Fals
     return torch.as_strided(storage, tuple(size), tuple(stride), storage_offset)
 
 
-def _rebuild_parameter(data, requires_grad=False, backward_hooks=None):
+def _rebuild_parameter(data, requires_grad=False, backward_hooks=None, state=None):
+    # torch._utils._rebuild_parameter (3 arguments) and _rebuild_parameter_with_state (4: + the Parameter's __dict__)
     return data
 
 

@@ -99,6 +99,10 @@ int dt_bn_finalize(float* stats, int P, int C, double count, const float* gamma,
 /* eval mode: scale/shift from running stats. */
 int dt_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* eval mode with a backward pass to follow (frozen-BatchNorm fine-tuning, F.batch_norm(training=False) backward):
+ * mean = running_mean, invstd = 1/sqrt(running_var + eps) for dt_bn_bwd_reduce / dt_bn_bwd_apply_frozen. */
+int dt_bn_eval_stats(const float* running_mean, const float* running_var, float eps, int C, float* mean,
+                     float* invstd, void* stream);
 /* out = act( y*scale[c]+shift[c] + (res ? res*rscale[c]+rshift[c] : 0) ), act = ReLU if relu!=0.
  * rscale/rshift NULL -> identity residual.  n_pix = B*H*W. */
 int dt_bn_act(const float* y, const float* scale, const float* shift, const float* res,
@@ -119,6 +123,12 @@ int dt_bn_bwd_apply(const float* dout, const float* out_act, const float* y, con
                     const float* invstd, const float* gamma, const float* act_scale, const float* act_shift,
                     float* red, int P, float* dgamma, float* dbeta, float* dy, float* dres, int dres_accumulate,
                     int64_t n_pix, int C, void* stream);
+/* the same pass for eval-mode (frozen-statistics) BatchNorm: dgamma = sum g*xhat, dbeta = sum g as above, but
+ * dy = gamma*invstd*g (mean / invstd do not depend on the batch) — ATen batch_norm_backward with train=False. */
+int dt_bn_bwd_apply_frozen(const float* dout, const float* out_act, const float* y, const float* mean,
+                           const float* invstd, const float* gamma, const float* act_scale, const float* act_shift,
+                           float* red, int P, float* dgamma, float* dbeta, float* dy, float* dres,
+                           int dres_accumulate, int64_t n_pix, int C, void* stream);
 
 /* ------------------------------------------------------------------ pooling / resampling (K4,K9 bwd) */
 /* max_pool2d(k=3,s=2,p=1) NHWC; argmax (uint8 window position, first max in scan order like ATen). */
@@ -205,6 +215,18 @@ int dt_seg_loss_bwd(const float* logits, const int64_t* labels, const float* dis
                     const float* wfocal, const float* wbound, const float* gscale, const float* wass_m,
                     const float* wass_coef, const float* gw_posgrad, float* dlogits, int B, int K, int H, int W,
                     void* stream);
+/* The scalar algebra of SemSegment.calculate_loss / log_metrics (segmodel.py:169-208; gdl.py:15-27,
+ * losses.py:187-291, gwdl.py:110-138, smp Fscore) on the [B][K][NACC] sums of dt_seg_loss_fwd, fp64, on the device:
+ *   parts fp32 [8] = dice_loss, boundary_loss, focal_loss, ce_loss, dice (Fscore w/o background), dice_with_bg,
+ *                    total_loss, total_loss (slot 7 = the differentiable scalar callers hand to backward);
+ *   coef [B][K][2], wfocal [2], wbound [K] and (GWDICE) wass_a [B] (-> dt_gwdice_posgrad), wass_c [B]: the inputs of
+ *   dt_seg_loss_bwd.  dice_kind 0 GDICE / 1 DICE / 2 GWDICE / 3 no dice term (single-loss callables); boundary_weight = alpha for BOUNDARY-RAMPED, else 1. */
+typedef struct dt_loss_cfg {
+  int32_t dice_kind, use_boundary, use_focal;
+  float boundary_weight, gamma;
+} dt_loss_cfg;
+int dt_seg_loss_algebra(const double* acc, const dt_loss_cfg* cfg, int B, int K, int H, int W, float* parts, float* coef,
+                        float* wfocal, float* wbound, float* wass_a, float* wass_c, void* stream);
 /* GWDICE position passes.  loss/gwdl.py:180-198 broadcasts alpha[B,1,S] * (1 - wass)[B,S] to [B,B,S], so sample
  * i's generalised true positives are sum_s alpha_i(s) * V(s), V(s) = sum_j (1 - wass_j(s)) over the whole batch
  * (equal to the published formula only for B = 1); reproduced because the reference trains with it.
@@ -337,6 +359,12 @@ int dt_clip_coef(const double* partial, int rows, float max_norm, float gscale, 
 int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, float bias_c1, float bias_c2, const float* clipcoef, const int32_t* skip_flag,
                  void* stream);
+/* skip_flag[0] = !isfinite(loss[0])  (segmodel.py:220-222: training_step returns None) */
+int dt_skip_from_loss(const float* loss, int32_t* skip_flag, void* stream);
+/* device-resident step count: t += (skip ? 0 : 1); hyper[3] = (lr_dev[0], 1 - beta1^t, 1 - beta2^t) for
+ * dt_adam_step_dev — a skipped step does not advance the bias correction (torch.optim.Adam is not called then) */
+int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_dev, float beta1, float beta2,
+                    float* hyper, void* stream);
 /* the same step with the per-step scalars on the device: hyper fp32 [3] = (lr, 1 - beta1^t, 1 - beta2^t), so a
  * training step captured in a HIP graph replays with the current learning rate and bias corrections. */
 int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,

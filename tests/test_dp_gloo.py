@@ -45,7 +45,8 @@ def _worker(rank, world, port, q):
                 return (u8[..., 0] > 127).to(torch.uint8)
         rng = np.random.default_rng(0)
         arr = rng.integers(0, 256, (4, 512, 512), dtype=np.uint8)
-        out = infer_tile(Fake(), arr, subtile=128, batch_size=4, rank=rank, world=world, device="cpu")
+        out = infer_tile(Fake(), arr, subtile=128, batch_size=4, rank=rank, world=world, device="cpu",
+                         tile_shape=(512, 512))
         ok2 = np.array_equal(out, (arr[0] > 127).astype(np.uint8))
         q.put((rank, bool(ok), bool(ok2)))
     finally:

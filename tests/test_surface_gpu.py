@@ -132,7 +132,7 @@ def test_inference_checkpoint_fused_argmax_and_tiles(tmp_path):
     assert tuple(single.shape) == (256, 256)                             # tests/test_inference.py:87-93 shape contract
     assert torch.equal(single.cpu(), am[0])
     # MI355X path: uint8 in, uint8 out, normalisation on the device; block merge bit-identical
-    merged = infer_tile(inf, arr, subtile=256, batch_size=2, device=DEV)
+    merged = infer_tile(inf, arr, subtile=256, batch_size=2, device=DEV, tile_shape=(512, 512))
     assert merged.dtype == np.uint8 and merged.shape == (512, 512)
     from deadtrees_amd.deployment.tiler import unmake_blocks_vectorized
     want_merged = unmake_blocks_vectorized([am.numpy().astype(np.uint8)], 256, 512, 512)
