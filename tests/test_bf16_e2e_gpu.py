@@ -7,8 +7,8 @@ Three levels, tightest first:
 1. teacher-forced: every intermediate tensor of one HIP training step (forward activations, BatchNorm
    coefficients, every activation gradient of the hand-scheduled backward) against what the oracle computes from
    the HIP path's OWN inputs of that unit.  No error can cascade, so the bound is accumulation accuracy:
-   relative L2 <= 2e-3 per tensor (measured ~1e-4: a fraction of a percent of elements off by one bf16 ulp),
-   parameter gradients <= 2e-3.  A wrong scale/shift pairing, a dropped residual, a missed join or a wrong
+   relative L2 <= 5e-4 per tensor (measured <= 1.2e-4 over 368 tensors x 4 configurations: a fraction of a percent
+   of the elements off by one bf16 ulp), parameter gradients <= 5e-5 (measured 1.2e-6).  A wrong scale/shift pairing, a dropped residual, a missed join or a wrong
    bucket shows up as an O(1) error in the unit that has it.
 2. free-running: bf16 rounding is discontinuous, so two evaluations that differ in accumulation ORDER decorrelate
    within a few layers (the oracle moves its own logits by 5-8 % when its input is perturbed by 1e-6 or its
@@ -43,7 +43,8 @@ def _hip_step(ref, img, mask, names=("GDICE", "FOCAL"), trace=True):
     eng = m.engine
     eng.trace = {} if trace else None
     logits = m(img.to(DEV))
-    S = dict(eng.saved.d)     # the backward pass clears the entries of the engine's dict, not the tensors
+    S = dict(logits.grad_fn.saved_acts.d)   # the autograd node owns the saved activations; backward clears the
+                                            # dict entries, not the tensors
     loss, _, err = seg_loss(logits, mask.to(DEV), None, names)
     loss.backward()
     torch.cuda.synchronize()
@@ -105,13 +106,14 @@ def test_bf16_train_step_teacher_forced_against_rounding_oracle(B, H, W, C, K, a
     grads_o = o.backward(lg.grad)
     assert not o.unforced, o.unforced                                        # every oracle tensor had a HIP twin
     worst = sorted(((v[0], k) for k, v in o.errs.items() if ".bn." not in k), reverse=True)
+    wbn = max((v[1], k) for k, v in o.errs.items() if ".bn." in k)
     print(f"[bf16 teacher-forced {B}x{H}x{W}x{C} K={K}] {len(o.errs)} tensors; worst rel-L2: " +
-          ", ".join(f"{k} {e:.1e}" for e, k in worst[:5]))
+          ", ".join(f"{k} {e:.1e}" for e, k in worst[:5]) + f"; worst BatchNorm coefficient {wbn[1]} {wbn[0]:.1e}")
     for k, (rel, mx) in o.errs.items():
         if ".bn." in k:       # per-channel fp32 coefficients: relative to the largest coefficient of the layer
             assert mx <= 2e-4, (k, rel, mx)
         else:                 # bf16 tensors / logits: accumulation-order rounding flips only
-            assert rel <= 2e-3, (k, rel, mx)
+            assert rel <= 5e-4, (k, rel, mx)
     gh = m.smp_grad_dict()
     assert set(gh) == set(grads_o)
     gscale = max(float(g.norm()) for g in grads_o.values())
@@ -119,7 +121,7 @@ def test_bf16_train_step_teacher_forced_against_rounding_oracle(B, H, W, C, K, a
     for k, g in grads_o.items():
         e = float((gh[k].double() - g.double()).norm())
         werr.append((e / (float(g.norm()) + 1e-30), k))
-        assert e <= 2e-3 * float(g.norm()) + 1e-5 * gscale, (k, e, float(g.norm()))
+        assert e <= 5e-5 * float(g.norm()) + 1e-6 * gscale, (k, e, float(g.norm()))
     print("   worst parameter-gradient rel-L2: " + ", ".join(f"{k} {e:.1e}" for e, k in sorted(werr, reverse=True)[:4]))
 
 
