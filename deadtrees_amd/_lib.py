@@ -43,6 +43,7 @@ SIGNATURES = {
     "dt_last_error": (C.c_char_p, []),
     "dt_version": (C.c_int, []),
     "dt_device_count": (C.c_int, []),
+    "dt_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "dt_conv2d_stat_rows": (C.c_int, [_P]),
     "dt_conv2d": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_config": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

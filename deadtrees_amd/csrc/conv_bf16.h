@@ -1,0 +1,23 @@
+// Argument block shared by the bf16 convolution kernels (conv_bf16.hip, conv_bf16_dma.hip).
+#pragma once
+#include "common.h"
+
+struct ConvBfArgs {
+  const __bf16* src0;
+  const __bf16* src1;
+  const __bf16* w;  // [tap][Cout][Cin]
+  const float* in_scale;
+  const float* in_shift;
+  __bf16* out;
+  __bf16* out1;     // channels >= cout_split (decoder concat data gradient)
+  float* stats;     // [2][P][Cout] BatchNorm partial sums from the fp32 accumulators, or null
+  // fused BatchNorm-backward reduction (dt_conv2d_bf16_bn_bwd): bnb.y (bf16, shape of `out`) set -> `stats` receives
+  // sum g, sum g*xhat of the layer this data gradient belongs to instead of sum v, sum v^2
+  dt_bn_bwd_fuse bnb;
+  int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, n_tiles, P, cout_split, accumulate;
+};
+
+// ---- LDS-DMA staged, double-buffered 3x3 stride-1 kernel (conv_bf16_dma.hip): 512-pixel x 64-channel tiles
+int dt_conv_bf16_dma_supported(const dt_conv_desc* d);
+int dt_conv_bf16_dma_launch(ConvBfArgs a, hipStream_t st);   // fills tiles_x / tiles_y / n_tiles / P itself
+int dt_conv_bf16_dma_stat_rows(const dt_conv_desc* d);

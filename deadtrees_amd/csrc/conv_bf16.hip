@@ -15,20 +15,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-struct ConvBfArgs {
-  const __bf16* src0;
-  const __bf16* src1;
-  const __bf16* w;  // [tap][Cout][Cin]
-  const float* in_scale;
-  const float* in_shift;
-  __bf16* out;
-  __bf16* out1;     // channels >= cout_split (decoder concat data gradient)
-  float* stats;     // [2][P][Cout] BatchNorm partial sums from the fp32 accumulators, or null
-  // fused BatchNorm-backward reduction (dt_conv2d_bf16_bn_bwd): bnb.y (bf16, shape of `out`) set -> `stats` receives
-  // sum g, sum g*xhat of the layer this data gradient belongs to instead of sum v, sum v^2
-  dt_bn_bwd_fuse bnb;
-  int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, n_tiles, P, cout_split, accumulate;
-};
+#include "conv_bf16.h"
 
 #define BF_CK 32      // channels per chunk of the wide kernels; LDS rows hold CK channels at a pitch of CK + 8 bf16:
                       // 80 B (CK 32) or 48 B (CK 16) — both keep every 8-lane ds_read_b128 / ds_write_b128 group on
@@ -456,6 +443,10 @@ static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_, int* ck_, int* mt_
     *tw_ = 32; *tn_ = 64; *ck_ = 16; *mt_ = 2;
     return;
   }
+  if (dt_conv_bf16_dma_supported(d)) {   // conv_bf16_dma.hip: 512-pixel x 64-channel tiles, 8 waves (reported as mt = 8)
+    *tw_ = 32; *tn_ = 64; *ck_ = 32; *mt_ = 8;
+    return;
+  }
   const int tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
   int tn = d->Cout >= 64 ? 64 : 32;
   if (d->cout_split > 0 && (d->cout_split % 64) != 0) tn = 32;
@@ -489,6 +480,7 @@ extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
   if (bf_validate(d) != DT_OK) return DT_EINVAL;
   int tw, tn, ck, mt;
   bf_cfg(d, &tw, &tn, &ck, &mt);
+  if (mt == 8) return dt_conv_bf16_dma_stat_rows(d);
   return d->B * dt_cdiv(d->Ho, 128 * mt / tw) * dt_cdiv(d->Wo, tw);
 }
 
@@ -538,6 +530,7 @@ static int conv2d_bf16_impl(const dt_conv_desc* d, const void* src0, const void*
   a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 128 * mt / tw); a.n_tiles = dt_cdiv(d->Cout, tn);
   a.P = d->B * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
+  if (mt == 8) return dt_conv_bf16_dma_launch(a, st);
   if (d->ksize == 4) {
     DT_REQUIRE(in_scale == nullptr && fuse == nullptr, "conv_bf16: the stem takes no input transform / fused reduction");
     return bf_launch<4, 1, 32, 64, 16, 2>(a, st);

@@ -355,8 +355,11 @@ class UNetEngine:
             nbytes = 2.0 * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
                                      desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
                 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
-            name = (f"conv_fwd_bf16_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, {mt.value}, "
-                    f"{'true' if in_ss else 'false'}>")
+            if mt.value == 8:     # the LDS-DMA staged 512-pixel kernel (conv_bf16_dma.hip)
+                name = f"conv3x3_bf16_dma_kernel<{'true' if in_ss else 'false'}>"
+            else:
+                name = (f"conv_fwd_bf16_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, "
+                        f"{mt.value}, {'true' if in_ss else 'false'}>")
             prof.append((name, flops, e0, e1, nbytes))
 
     # ---- weight gradients run on a side stream, concurrently with the data-gradient chain of the main stream:

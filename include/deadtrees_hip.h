@@ -370,6 +370,13 @@ int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_de
 int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
                      float beta2, float eps, const float* clipcoef, const int32_t* skip_flag, void* stream);
 
+/* ------------------------------------------------------------------ library options */
+/* Kernel-selection switches (host side, process wide; every choice computes the same values):
+ *   "bf16_dma": 0 = register-staged bf16 convolutions only, 1 (default) = the LDS-DMA staged 512-pixel kernel where
+ *               its tiles fill the chip, 2 = wherever its shape conditions hold.  Also read from the environment
+ *               variable DT_BF16_DMA at first use. */
+int dt_set_option(const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,17 +70,30 @@ for name, H, W, C0, C1, mode0, Cout, k, s, p in SHAPES:
         s0, s1 = src0.to(bf), (src1.to(bf) if src1 is not None else None)
         wp = ops.pack_weights_bf16(w)
         if k in (1, 3) and C0 % 8 == 0:
+            from deadtrees_amd import _lib
+            lib = _lib.load()
             out0, _, _ = ops.conv2d_bf16(s0, wp, k, s, p, Cout, src1=s1, mode0=mode0, want_stats=True)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                ops.conv2d_bf16(s0, wp, k, s, p, Cout, src1=s1, mode0=mode0, want_stats=True, out0=out0)
-            e1.record()
-            torch.cuda.synchronize()
-            t = e0.elapsed_time(e1) / reps * 1e-3
+            # A/B in one process, interleaved rounds: register-staged kernels (0) vs the LDS-DMA kernel where it applies (2)
+            times = {0: [], 2: []}
+            for rnd in range(3):
+                for mode in (0, 2):
+                    lib.dt_set_option(b"bf16_dma", mode)
+                    ops.conv2d_bf16(s0, wp, k, s, p, Cout, src1=s1, mode0=mode0, want_stats=True, out0=out0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        ops.conv2d_bf16(s0, wp, k, s, p, Cout, src1=s1, mode0=mode0, want_stats=True, out0=out0)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    times[mode].append(e0.elapsed_time(e1) / reps * 1e-3)
+            lib.dt_set_option(b"bf16_dma", 1)
+            t = min(times[0])
             res["bf16_fwd_us"] = round(t * 1e6, 1)
             res["bf16_fwd_TF"] = round(flops / t / 1e12, 1)
+            t2 = min(times[2])
+            res["bf16_dma_us"] = round(t2 * 1e6, 1)
+            res["bf16_dma_TF"] = round(flops / t2 / 1e12, 1)
             dyb = torch.randn((B, Ho, Wo, Cout), generator=g).to(bf).cuda()
             ops.conv2d_wgrad_bf16(s0, dyb, k, s, p, src1=s1, mode0=mode0)
             torch.cuda.synchronize()

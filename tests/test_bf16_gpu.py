@@ -361,3 +361,81 @@ def test_conv_bf16_gradient_join_with_fused_bn_backward_reduction(B, H, W, Cin, 
     scale = float(gm.abs().sum(dim=(0, 2, 3)).max()) + 1.0
     assert float((sums[0] - gm.sum(dim=(0, 2, 3))).abs().max()) <= 3e-5 * scale
     assert float((sums[1] - (gm * xh).sum(dim=(0, 2, 3))).abs().max()) <= 1e-4 * scale
+
+
+# ---------------------------------------------------------------- LDS-DMA staged 512-pixel kernel (conv_bf16_dma.hip)
+def _set_dma(mode):
+    from deadtrees_amd import _lib
+    _lib.check(_lib.load().dt_set_option(b"bf16_dma", mode), "dt_set_option")
+
+
+DMA_CASES = [  # B, H, W (stored size of source 0), C0, C1, mode0, Cout, split, transform
+    (2, 32, 32, 64, 0, 0, 64, 0, False), (1, 34, 70, 512, 0, 0, 64, 0, True), (3, 17, 33, 32, 0, 0, 128, 0, False),
+    (2, 16, 20, 64, 32, 1, 128, 0, True), (2, 16, 24, 128, 64, 1, 64, 0, False), (2, 40, 48, 64, 0, 0, 192, 64, False),
+    (1, 64, 64, 96, 0, 2, 64, 0, False)]
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,split,tf", DMA_CASES)
+def test_conv_bf16_dma_kernel_is_bit_identical_to_the_register_staged_kernel(B, H, W, C0, C1, mode0, Cout, split, tf):
+    """the LDS-DMA staged, double-buffered kernel against the register-staged one on the same operands: same MFMA
+    sequence per output element -> bit-identical outputs and BatchNorm partial sums (hence every parity test of the
+    old kernel carries over); ragged right / bottom edges, several images, 1..16 channel chunks, the producer's
+    BatchNorm + ReLU fused into the staging, nearest x2 upsample + concat, zero insertion, split outputs + gradient join."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + H + C0 + Cout)
+    Hin, Win = (H, W) if mode0 == 0 else (2 * H, 2 * W)
+    x = torch.randn((B, H, W, C0), generator=g).to(BF).to(DEV)   # mode0 1 / 2: stored at half resolution
+    s1 = torch.randn((B, Hin, Win, C1), generator=g).to(BF).to(DEV) if C1 else None
+    w = (torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5).to(DEV)
+    wp = ops.pack_weights_bf16(w)
+    sc = (1 + 0.3 * torch.randn(C0, generator=g)).to(DEV) if tf else None
+    sh = (0.3 * torch.randn(C0, generator=g) + 0.2).to(DEV) if tf else None
+    res = {}
+    try:
+        for mode in (0, 2):
+            _set_dma(mode)
+            kw = dict(src1=s1, mode0=mode0, in_scale=sc, in_shift=sh)
+            if split:
+                base0 = torch.randn((B, Hin, Win, split), generator=torch.Generator().manual_seed(1)).to(BF).to(DEV)
+                o0, o1, _ = ops.conv2d_bf16(x, wp, 3, 1, 1, Cout, split=split, out0=base0.clone(), accumulate=True, **kw)
+                res[mode] = (o0, o1, None)
+            else:
+                o0, _, st = ops.conv2d_bf16(x, wp, 3, 1, 1, Cout, want_stats=True, **kw)
+                res[mode] = (o0, None, st.sum(1))      # tile sizes differ: compare the per-channel totals
+    finally:
+        _set_dma(1)
+    a, bq = res[0], res[2]
+    assert torch.equal(a[0], bq[0])
+    if a[1] is not None:
+        assert torch.equal(a[1], bq[1])
+    if a[2] is not None:
+        np.testing.assert_allclose(a[2].cpu().numpy(), bq[2].cpu().numpy(), rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("join", [False, True])
+def test_conv_bf16_dma_kernel_fused_bn_backward_sums(join):
+    """dt_conv2d_bf16_bn_bwd on the DMA kernel: gradient bit-identical, BatchNorm-backward partial sums equal to the
+    register-staged kernel's per-channel totals (virtual activation / stored activation + gradient join)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5 + join)
+    B, H, W, Cin, Cout = 2, 40, 36, 64, 128
+    dy = torch.randn((B, H, W, Cin), generator=g).to(BF).to(DEV)
+    wp = ops.pack_weights_bf16((torch.randn((3, 3, Cin, Cout), generator=g) * 0.05).to(DEV), dgrad=False)
+    y = (torch.randn((B, H, W, Cout), generator=g) * 1.5 + 0.2).to(BF).to(DEV)
+    mean = y.float().mean(dim=(0, 1, 2)).contiguous()
+    invstd = (1.0 / torch.sqrt(y.float().var(dim=(0, 1, 2), unbiased=False) + 1e-5)).contiguous()
+    sc = (1 + 0.2 * torch.randn(Cout, generator=g)).to(DEV)
+    sh = (0.2 * torch.randn(Cout, generator=g)).to(DEV)
+    act = torch.relu(y.float() * sc + sh).to(BF) if join else None
+    base = torch.randn((B, H, W, Cout), generator=g).to(BF).to(DEV) if join else None
+    res = {}
+    try:
+        for mode in (0, 2):
+            _set_dma(mode)
+            out, red = ops.conv2d_bf16_bn_bwd(dy, wp, Cout, y, mean, invstd, None if join else sc, None if join else sh,
+                                              act=act, join_into=base.clone() if join else None)
+            res[mode] = (out, red.sum(1))
+    finally:
+        _set_dma(1)
+    assert torch.equal(res[0][0], res[2][0])
+    np.testing.assert_allclose(res[0][1].cpu().numpy(), res[2][1].cpu().numpy(), rtol=2e-5, atol=2e-3)
