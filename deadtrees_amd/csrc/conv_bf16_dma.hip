@@ -40,6 +40,7 @@ typedef void __attribute__((address_space(3)))* dm_lptr;
 #define DM_TF_MAXC 512
 #define DM_LDS (DM_TF_OFF + 2 * DM_TF_MAXC * 4)        // 157,696 B of the CU's 163,840
 #define DM_PPW 5                                       // pieces per wave and operand (8 waves)
+#define DM_MAX_WGS 256                                 // CUs of an MI355X
 
 __device__ __attribute__((aligned(64))) unsigned dm_zero_block[16];
 
@@ -47,12 +48,16 @@ __device__ __forceinline__ void dm_dma16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((dm_gptr)g, (dm_lptr)l, 16, 0, 0);
 }
 
-template <bool TF>
-__global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfArgs a) {
+// EPI selects the epilogue at compile time (register pressure: the persistent loop keeps the accumulators, the next
+// tile's staging context and the epilogue's state live together): 0 plain store (+ BatchNorm statistics, split
+// outputs), 1 plain store + fused BatchNorm-backward sums (virtual activation), 2 gradient join (fp32 staging, split
+// outputs), 3 gradient join + fused BatchNorm-backward sums (stored activation).
+template <bool TF, int EPI>
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfArgs a, int total_tiles) {
   constexpr int TN = DM_TN, NT = TN / 32;
   constexpr int OUT_PITCH = TN + 8;    // bf16 per pixel row of the store-staging image
   constexpr int OUTF_PITCH = TN + 4;   // fp32 per pixel row of the gradient-join staging image
-  static_assert(256 * OUTF_PITCH * 4 <= DM_BUF, "one epilogue staging image per 256-pixel half inside one buffer");
+  static_assert(256 * OUTF_PITCH * 4 <= DM_BUF, "the epilogue staging image of a 256-pixel half fits one buffer");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[DM_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,73 +69,85 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
       lds_tf[DM_TF_MAXC + i] = a.in_shift[i];
     }
   }
-  const int wg = (int)xcd_remap(blockIdx.x, gridDim.x);
-  const int nt = wg % a.n_tiles, sp = wg / a.n_tiles;
-  const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
-  const int oy0 = ty * DM_TH, ox0 = tx * DM_TW, n0 = nt * TN;
-  const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
   const int Cin = a.C0 + a.C1;
   const int Hs0 = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.mode0 ? (a.Win >> 1) : a.Win;
+  const int nchunks = Cin / 32;
+  const int G = gridDim.x;
 
-  // ---- staging bookkeeping.  Piece p (1 KiB) = LDS rows 16p .. 16p+15; lane l fills slot (l & 3) of row 16p + (l >> 2)
-  // with channel segment seg = slot ^ ((row >> 2) & 3) = (l & 3) ^ ((l >> 4) & 3) of that row's pixel / weight row.
+  // ---- staging.  Piece p (1 KiB) = LDS rows 16p .. 16p+15; lane l fills slot (l & 3) of row 16p + (l >> 2) with
+  // channel segment seg = slot ^ ((row >> 2) & 3) = (l & 3) ^ ((l >> 4) & 3) of that row's pixel / weight row.
+  // The staging context (which tile / chunk the next DMA belongs to) runs one step ahead of the multiplication.
   const int seg = (lane & 3) ^ ((lane >> 4) & 3);
   int pix0[DM_PPW], pix1[DM_PPW], woff[DM_PPW];
-#pragma unroll
-  for (int i = 0; i < DM_PPW; ++i) {
-    const int row = (wave + 8 * i) * 16 + (lane >> 2);
-    const int hy = row / DM_HW, hx = row - hy * DM_HW;
-    const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool inb = row < DM_IN_ROWS && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-    bool ok0 = inb;
-    if (a.mode0 == 2) ok0 = ok0 && (((iy | ix) & 1) == 0);   // zero insertion (transposed convolution)
-    const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
-    pix0[i] = ok0 ? (b * Hs0 + sy) * Ws0 + sx : -1;
-    pix1[i] = inb ? (b * a.Hin + iy) * a.Win + ix : -1;
-    const int wrow = (wave + 8 * i) * 16 + (lane >> 2);      // tap * 64 + n
-    woff[i] = ((wrow >> 6) * a.Cout + n0 + (wrow & 63)) * Cin + 8 * seg;
-  }
-  const __bf16* zsrc = reinterpret_cast<const __bf16*>(dm_zero_block);
-
-  auto dma_weights = [&](int c0, int buf) {
+  int s_tile = blockIdx.x, s_chunk = 0;        // tile id (before the XCD remap) and chunk of the next staging step
+  auto stage_setup = [&](int tile_id) {
+    const int wg = (int)xcd_remap((unsigned)tile_id, (unsigned)total_tiles);
+    const int nt = wg % a.n_tiles, sp = wg / a.n_tiles;
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int iy0 = ty * DM_TH - a.pad, ix0 = tx * DM_TW - a.pad, n0 = nt * TN;
 #pragma unroll
     for (int i = 0; i < DM_PPW; ++i) {
-      const int wp = wave + 8 * i;
-      if (wp < DM_W_PIECES) dm_dma16(a.w + (size_t)woff[i] + c0, lds + buf + (DM_IN_PIECES + wp) * 1024);
+      const int row = (wave + 8 * i) * 16 + (lane >> 2);
+      const int hy = row / DM_HW, hx = row - hy * DM_HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool inb = row < DM_IN_ROWS && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      bool ok0 = inb;
+      if (a.mode0 == 2) ok0 = ok0 && (((iy | ix) & 1) == 0);   // zero insertion (transposed convolution)
+      const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
+      pix0[i] = ok0 ? (b * Hs0 + sy) * Ws0 + sx : -1;
+      pix1[i] = inb ? (b * a.Hin + iy) * a.Win + ix : -1;
+      woff[i] = ((row >> 6) * a.Cout + n0 + (row & 63)) * Cin + 8 * seg;   // weight row = tap * 64 + n
     }
   };
-  auto dma_input = [&](int c0, int buf) {
+  const __bf16* zsrc = reinterpret_cast<const __bf16*>(dm_zero_block);
+  f32x4 rin[TF ? DM_PPW : 1];     // a virtual input activation passes through registers
+  unsigned rin_valid = 0;
+  int rin_c0 = 0;
+  // The staging of step (s_tile, s_chunk) into buffer `buf` is 10 pieces per wave — 5 of the weight image, 5 of the
+  // input image: DMA (or, for inputs that still need the producer's BatchNorm + ReLU, register loads) — issued one at
+  // a time between the MFMA groups of the step being multiplied, then the staging context advances.
+  auto stage_piece = [&](int k, int buf) {
+    const int c0 = 32 * s_chunk;
+    if (k < DM_PPW) {
+      const int wp = wave + 8 * k;
+      if (wp < DM_W_PIECES) dm_dma16(a.w + (size_t)woff[k] + c0, lds + buf + (DM_IN_PIECES + wp) * 1024);
+      return;
+    }
+    const int i = k - DM_PPW;
     const bool use0 = c0 < a.C0;
     const __bf16* src = use0 ? a.src0 : a.src1;
     const int C = use0 ? a.C0 : a.C1;
     const int cc = (use0 ? c0 : c0 - a.C0) + 8 * seg;
-#pragma unroll
-    for (int i = 0; i < DM_PPW; ++i) {
-      const int ip = wave + 8 * i;
+    const int p = use0 ? pix0[i] : pix1[i];
+    const int ip = wave + 8 * i;
+    if constexpr (TF) {
+      if (i == 0) {
+        rin_valid = 0;
+        rin_c0 = c0;
+      }
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ip < DM_IN_PIECES && p >= 0) {
+        v = *reinterpret_cast<const f32x4*>(src + (size_t)p * C + cc);
+        rin_valid |= 1u << i;
+      }
+      rin[TF ? i : 0] = v;
+    } else {
       if (ip < DM_IN_PIECES) {
-        const int p = use0 ? pix0[i] : pix1[i];
         const __bf16* g = p >= 0 ? src + (size_t)p * C + cc : zsrc;
         dm_dma16(g, lds + buf + ip * 1024);
       }
     }
   };
-  // virtual input activation: the chunk passes through registers (load early, transform + ds_write after the barrier)
-  f32x4 rin[TF ? DM_PPW : 1];
-  auto load_input = [&](int c0) {
-    const bool use0 = c0 < a.C0;
-    const __bf16* src = use0 ? a.src0 : a.src1;
-    const int C = use0 ? a.C0 : a.C1;
-    const int cc = (use0 ? c0 : c0 - a.C0) + 8 * seg;
-#pragma unroll
-    for (int i = 0; i < DM_PPW; ++i) {
-      const int p = use0 ? pix0[i] : pix1[i];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (wave + 8 * i < DM_IN_PIECES && p >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)p * C + cc);
-      rin[TF ? i : 0] = v;
+  auto stage_advance = [&]() {
+    if (++s_chunk == nchunks) {
+      s_chunk = 0;
+      s_tile += G;
+      if (s_tile < total_tiles) stage_setup(s_tile);
     }
   };
-  auto write_input = [&](int c0, int buf) {
-    const int cc = c0 + 8 * seg;
+  // registers -> LDS for the chunk loaded by the last stage_issue (transform applied; padding stays zero)
+  auto stage_write = [&](int buf) {
+    const int cc = rin_c0 + 8 * seg;
     const bool tf_on = cc < a.C0;
     float sc[8], sh[8];
     if (tf_on) {
@@ -145,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
       const int ip = wave + 8 * i;
       if (ip < DM_IN_PIECES) {
         f32x4 raw = rin[TF ? i : 0];
-        if (tf_on && pix0[i] >= 0) {     // padding stays zero
+        if (tf_on && ((rin_valid >> i) & 1u)) {
           bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -161,235 +178,290 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
   };
 
   // ---- fragment read addresses (bytes inside a buffer).  A: halo pixel q, k-segment g = 2 ks + h -> q*64 + 16*(g ^ sw(q))
-  int abase[9][2];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int q = (2 * wave + m + tap / 3) * DM_HW + r + tap % 3;
-      abase[tap][m] = q * 64 + ((((q >> 2) & 3) ^ h) << 4);
-    }
+  // (recomputed per chunk from qb: 18 precomputed addresses would cost 18 VGPRs for the whole persistent loop)
+  int qb = 2 * wave * DM_HW + r;
   const int bbase = DM_IN_PIECES * 1024 + r * 64 + ((((r >> 2) & 3) ^ h) << 4);   // + tap*4096 + j*2048, ^ (ks << 5)
 
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+  // epilogue roles: every thread moves 16-byte segment sg of pixel rows prow, prow + 64, ... of a 256-pixel half
+  constexpr int SEGS = TN / 8, PER_IT = 512 / SEGS, ITS = 256 / PER_IT;
+  const int sg = tid % SEGS, prow = tid / SEGS;
+  const int hf = wave >> 2, lw = wave & 3;
+  constexpr bool bnb = (EPI & 1) != 0, JOIN = (EPI & 2) != 0;
 
-  // ---- pipeline: chunk c+1 is staged into the other buffer while chunk c is multiplied; one barrier per chunk
-  const int nchunks = Cin / 32;
+  // ---- persistent loop over this workgroup's tiles; the chunks of consecutive tiles form ONE pipelined stream:
+  // while chunk s is multiplied the DMA of chunk s+1 (possibly the next tile's first) fills the other buffer, so a
+  // tile's epilogue and the next tile's first loads overlap.  One barrier per chunk + four per tile.
   if constexpr (TF) __syncthreads();   // the transform table
-  dma_weights(0, 0);
-  if constexpr (TF) {
-    load_input(0);
-    write_input(0, 0);
-    if (nchunks > 1) load_input(32);
-  } else {
-    dma_input(0, 0);
+#if defined(DM_ABLATE) && DM_ABLATE >= 3
+  if (false) {
+#else
+  if (s_tile < total_tiles) {
+#endif
+    stage_setup(s_tile);
+#pragma unroll
+    for (int k = 0; k < 2 * DM_PPW; ++k) stage_piece(k, 0);
+    stage_advance();
+    if constexpr (TF) stage_write(0);
   }
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = (c & 1) * DM_BUF, nxt = DM_BUF - cur;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of chunk c have landed
-    __syncthreads();                                   // ... everybody's; and everybody is done reading buffer `nxt`
-    if (c + 1 < nchunks) {
-      dma_weights(32 * (c + 1), nxt);
-      if constexpr (TF) {
-        write_input(32 * (c + 1), nxt);
-        if (c + 2 < nchunks) load_input(32 * (c + 2));
-      } else {
-        dma_input(32 * (c + 1), nxt);
-      }
-    }
-    const unsigned char* bufp = lds + cur;
+  int step = 0;
+  for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
+    const int wg = (int)xcd_remap((unsigned)tile, (unsigned)total_tiles);
+    const int nt = wg % a.n_tiles, sp = wg / a.n_tiles;
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * DM_TH, ox0 = tx * DM_TW, n0 = nt * TN;
+    f32x16 acc[2][NT];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 av[2], bv[NT];
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const bf16x8*>(bufp + (abase[tap][m] ^ (ks << 5)));
+        for (int i = 0; i < 16; ++i) acc[m][j][i] = 0.f;
+    int cur = 0;
+    for (int c = 0; c < nchunks; ++c, ++step) {
+      cur = (step & 1) * DM_BUF;
+      const int nxt = DM_BUF - cur;
+#if !(defined(DM_ABLATE) && DM_ABLATE >= 3)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of this step have landed
+#endif
+      __syncthreads();                                   // ... everybody's; and nobody still reads buffer `nxt`
+#if defined(DM_ABLATE) && (DM_ABLATE == 1 || DM_ABLATE >= 3)   // throw-away measurement build: no staging after the first step
+      const bool more = false;
+#else
+      const bool more = s_tile < total_tiles;
+#endif
+      const unsigned char* bufp = lds + cur;
+      asm volatile("" : "+v"(qb));   // keep the address arithmetic below inside the loop (see qb)
+      // 18 k-steps (tap, ks) of 4 MFMAs; the fragments of step t+1 are requested before the MFMAs of step t are issued
+      // (two named register sets, everything unrolled), so a wave's LDS latency hides under its own matrix work and
+      // the compiler's waits become counted (lgkmcnt(4)) instead of a drain before every MFMA group
+      bf16x8 fa[2][2], fb[2][NT];
+      auto frag_load = [&](int t, bf16x8 (&av)[2], bf16x8 (&bv)[NT]) {
+        const int tap = t >> 1, ks = t & 1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int q = qb + (m + tap / 3) * DM_HW + tap % 3;
+          av[m] = *reinterpret_cast<const bf16x8*>(bufp + ((q * 64 + ((((q >> 2) & 3) ^ h) << 4)) ^ (ks << 5)));
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           bv[j] = *reinterpret_cast<const bf16x8*>(bufp + (bbase ^ (ks << 5)) + tap * 4096 + j * 2048);
+      };
+      auto frag_mma = [&](const bf16x8 (&av)[2], const bf16x8 (&bv)[NT]) {
+#if defined(DM_ABLATE) && DM_ABLATE == 2     // throw-away measurement build: staging and fragment reads only
+        asm volatile("" ::"v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
+        return;
+#endif
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], bv[j], acc[m][j], 0, 0, 0);
+      };
+      // `frag_ready` touches the current fragments: hipcc puts its `s_waitcnt lgkmcnt(0)` THERE, i.e. before the next
+      // step's reads are issued, so the wait covers only reads that already had a whole MFMA group to complete
+      // (left to itself it drains the reads it has just issued in front of every MFMA group)
+      auto frag_ready = [&](const bf16x8 (&av)[2], const bf16x8 (&bv)[NT]) {
+        asm volatile("" ::"v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
+      };
+      frag_load(0, fa[0], fb[0]);
+#pragma unroll
+      for (int t = 0; t < 18; t += 2) {
+        frag_ready(fa[0], fb[0]);
+        frag_load(t + 1, fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);   // reads first: they then have the whole MFMA group to complete
+        frag_mma(fa[0], fb[0]);
+        if (more && t < 2 * DM_PPW) stage_piece(t, nxt);          // the matrix pipe works on while the wave issues it
+        __builtin_amdgcn_sched_barrier(0);
+        frag_ready(fa[1], fb[1]);
+        if (t + 2 < 18) frag_load(t + 2, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mma(fa[1], fb[1]);
+        if (more && t + 1 < 2 * DM_PPW) stage_piece(t + 1, nxt);
+        if (more && t + 1 == 2 * DM_PPW - 1) stage_advance();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (TF) {
+        if (more) stage_write(nxt);
       }
     }
-  }
 
-  // ---- epilogue (the arithmetic of conv_fwd_bf16_kernel): D col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*h.
-  // The tile's two 256-pixel halves (waves 0-3 / 4-7) go through their own staging image at the same time.
-  const int hf = wave >> 2, lw = wave & 3, t256 = tid & 255;
-  __bf16* st16 = reinterpret_cast<__bf16*>(lds + hf * DM_BUF);
-  float* st32 = reinterpret_cast<float*>(lds + hf * DM_BUF);
-  float s1[NT], s2[NT];
+#if defined(DM_ABLATE) && DM_ABLATE == 4     // throw-away measurement build: no epilogue
 #pragma unroll
-  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-  const bool second = a.cout_split > 0 && n0 >= a.cout_split;
-  const int ld_all = a.cout_split > 0 ? (second ? a.Cout - a.cout_split : a.cout_split) : a.Cout;
-  __bf16* outp = second ? a.out1 : a.out;
-  const int nn0 = second ? n0 - a.cout_split : n0;
-  const bool join = a.accumulate && !second;
-  constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS;
-  const int sg = t256 % SEGS, prow = t256 / SEGS;
-  const bool bnb = a.bnb.y != nullptr;
-  float q1[8], q2[8], b_mu[8], b_is[8], b_sc[8], b_sh[8];
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) q1[k] = q2[k] = b_mu[k] = b_is[k] = b_sc[k] = b_sh[k] = 0.f;
-  if (bnb) {
-    auto ld8 = [&](const float* p, float (&v)[8]) {
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg), hi = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg + 4);
+      for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[m][j]));
+    continue;
+#endif
+    // ---- epilogue (the arithmetic of conv_fwd_bf16_kernel): D col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*h.
+    // The buffer just multiplied from (`cur`) is the staging image; the other one is receiving the next step's operands.
+    // The tile's two 256-pixel halves (waves 0-3 / 4-7) pass through it one after the other, all 512 threads storing.
+    __bf16* st16 = reinterpret_cast<__bf16*>(lds + cur);
+    float* st32 = reinterpret_cast<float*>(lds + cur);
+    float s1[NT], s2[NT];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[k] = lo[k];
-        v[4 + k] = hi[k];
-      }
-    };
-    ld8(a.bnb.mean, b_mu);
-    ld8(a.bnb.invstd, b_is);
-    if (a.bnb.act == nullptr) {
-      ld8(a.bnb.act_scale, b_sc);
-      ld8(a.bnb.act_shift, b_sh);
-    }
-  }
-  const int pbase = hf * 256;
-  __syncthreads();   // every wave is done with the operand images
-  if (!join) {
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    const bool second = a.cout_split > 0 && n0 >= a.cout_split;
+    const int ld_all = a.cout_split > 0 ? (second ? a.Cout - a.cout_split : a.cout_split) : a.Cout;
+    __bf16* outp = second ? a.out1 : a.out;
+    const int nn0 = second ? n0 - a.cout_split : n0;
+    // a split data gradient joins only into its first output (host: EPI 2 <=> accumulate)
+    const bool join = JOIN && !second;
+    float q1[8], q2[8], b_mu[8], b_is[8], b_sc[8], b_sh[8];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int pl = (lw * 2 + m2) * 32 + mrow;
-          const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
-          const float v = acc[m2][j][i];
-          if (oy < a.Ho && ox < a.Wo) {
-            s1[j] += v;
-            s2[j] += v * v;
-          }
-          st16[pl * OUT_PITCH + 32 * j + r] = (__bf16)v;
-        }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < SEGS; ++it) {
-      const int pl = prow + it * PER_IT;
-      const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
-      if (oy < a.Ho && ox < a.Wo) {
-        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * sg;
-        const f32x4 raw = *reinterpret_cast<const f32x4*>(st16 + pl * OUT_PITCH + 8 * sg);
-        *reinterpret_cast<f32x4*>(outp + o) = raw;
-        if (bnb) {   // plain store: virtual activation (host check) — the arithmetic of bn_bwd_reduce_bf16_kernel
-          const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + o);
-          const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&raw), yv = *reinterpret_cast<const bf16x8*>(&yraw);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float yk = (float)yv[k];
-            const float act = (float)(__bf16)(yk * b_sc[k] + b_sh[k]);
-            const float g = act > 0.f ? (float)gv[k] : 0.f;
-            q1[k] += g;
-            q2[k] += g * ((yk - b_mu[k]) * b_is[k]);
-          }
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int pl = (lw * 2 + m2) * 32 + mrow;
-          st32[pl * OUTF_PITCH + 32 * j + r] = acc[m2][j][i];
-        }
-    __syncthreads();
-    f32x4 prev[SEGS];
-#pragma unroll
-    for (int it = 0; it < SEGS; ++it) {
-      const int pl = prow + it * PER_IT;
-      const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (oy < a.Ho && ox < a.Wo)
-        v = *reinterpret_cast<const f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * sg);
-      prev[it] = v;
-    }
-#pragma unroll
-    for (int it = 0; it < SEGS; ++it) {
-      const int pl = prow + it * PER_IT;
-      const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
-      if (oy < a.Ho && ox < a.Wo) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(st32 + pl * OUTF_PITCH + 8 * sg);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(st32 + pl * OUTF_PITCH + 8 * sg + 4);
-        bf16x8 o = *reinterpret_cast<bf16x8*>(&prev[it]);
+    for (int k = 0; k < 8; ++k) q1[k] = q2[k] = b_mu[k] = b_is[k] = b_sc[k] = b_sh[k] = 0.f;
+    if (bnb) {
+      auto ld8 = [&](const float* p, float (&v)[8]) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg), hi = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg + 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          o[k] = (__bf16)(lo[k] + (float)o[k]);
-          o[4 + k] = (__bf16)(hi[k] + (float)o[4 + k]);
+          v[k] = lo[k];
+          v[4 + k] = hi[k];
         }
-        const size_t oo = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * sg;
-        *reinterpret_cast<bf16x8*>(outp + oo) = o;
-        if (bnb) {   // sums over the joined (rounded) gradient, mask from the stored activation
-          const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + oo);
-          const f32x4 zraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.act) + oo);
-          const bf16x8 yv = *reinterpret_cast<const bf16x8*>(&yraw), zv = *reinterpret_cast<const bf16x8*>(&zraw);
+      };
+      ld8(a.bnb.mean, b_mu);
+      ld8(a.bnb.invstd, b_is);
+      if constexpr (!JOIN) {
+        ld8(a.bnb.act_scale, b_sc);
+        ld8(a.bnb.act_shift, b_sh);
+      }
+    }
+    if (!bnb && !JOIN && a.stats != nullptr) {   // BatchNorm statistics from the fp32 accumulators
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float yk = (float)yv[k];
-            const float g = (float)zv[k] > 0.f ? (float)o[k] : 0.f;
-            q1[k] += g;
-            q2[k] += g * ((yk - b_mu[k]) * b_is[k]);
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int pt = (wave * 2 + m2) * 32 + mrow;
+            const float v = acc[m2][j][i];
+            if (oy0 + pt / DM_TW < a.Ho && ox0 + pt % DM_TW < a.Wo) {
+              s1[j] += v;
+              s2[j] += v * v;
+            }
+          }
+    }
+#pragma unroll 1
+    for (int hh = 0; hh < 2; ++hh) {
+      const int pbase = hh * 256;
+      __syncthreads();   // the staging image is free: operand reads / the other half's stores are done
+      if (hf == hh) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
+              const int pl = (lw * 2 + m2) * 32 + mrow;
+              if (join) st32[pl * OUTF_PITCH + 32 * j + r] = acc[m2][j][i];
+              else st16[pl * OUT_PITCH + 32 * j + r] = (__bf16)acc[m2][j][i];
+            }
+      }
+      __syncthreads();
+      if (!JOIN || !join) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int pl = prow + it * PER_IT;
+          const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
+          if (oy < a.Ho && ox < a.Wo) {
+            const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * sg;
+            const f32x4 raw = *reinterpret_cast<const f32x4*>(st16 + pl * OUT_PITCH + 8 * sg);
+            *reinterpret_cast<f32x4*>(outp + o) = raw;
+            if constexpr (bnb && !JOIN) {   // virtual activation — the arithmetic of bn_bwd_reduce_bf16_kernel
+              const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + o);
+              const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&raw), yv = *reinterpret_cast<const bf16x8*>(&yraw);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float yk = (float)yv[k];
+                const float act = (float)(__bf16)(yk * b_sc[k] + b_sh[k]);
+                const float g = act > 0.f ? (float)gv[k] : 0.f;
+                q1[k] += g;
+                q2[k] += g * ((yk - b_mu[k]) * b_is[k]);
+              }
+            }
+          }
+        }
+      } else if constexpr (JOIN) {
+        f32x4 prev[ITS];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int pl = prow + it * PER_IT;
+          const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (oy < a.Ho && ox < a.Wo)
+            v = *reinterpret_cast<const f32x4*>(outp + (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * sg);
+          prev[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int pl = prow + it * PER_IT;
+          const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
+          if (oy < a.Ho && ox < a.Wo) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(st32 + pl * OUTF_PITCH + 8 * sg);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(st32 + pl * OUTF_PITCH + 8 * sg + 4);
+            bf16x8 o = *reinterpret_cast<bf16x8*>(&prev[it]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              o[k] = (__bf16)(lo[k] + (float)o[k]);
+              o[4 + k] = (__bf16)(hi[k] + (float)o[4 + k]);
+            }
+            const size_t oo = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * sg;
+            *reinterpret_cast<bf16x8*>(outp + oo) = o;
+            if constexpr (bnb && JOIN) {   // sums over the joined (rounded) gradient, mask from the stored activation
+              const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + oo);
+              const f32x4 zraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.act) + oo);
+              const bf16x8 yv = *reinterpret_cast<const bf16x8*>(&yraw), zv = *reinterpret_cast<const bf16x8*>(&zraw);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float yk = (float)yv[k];
+                const float g = (float)zv[k] > 0.f ? (float)o[k] : 0.f;
+                q1[k] += g;
+                q2[k] += g * ((yk - b_mu[k]) * b_is[k]);
+              }
+            }
           }
         }
       }
     }
-  }
-  if (a.stats != nullptr && bnb) {
-    // per-thread sums over its pixels of 8 channels -> per-channel sums over the 2 x 32 threads of a channel segment
-    __syncthreads();
-    float* qs = reinterpret_cast<float*>(lds);   // [2 halves][2][8][256]
+    if (bnb) {
+      // per-thread sums over its pixels of 8 channels -> per-channel sums over the 64 threads of a channel segment
+      __syncthreads();
+      float* qs = reinterpret_cast<float*>(lds + cur);   // [2][8][512]
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      qs[(hf * 16 + k) * 256 + t256] = q1[k];
-      qs[(hf * 16 + 8 + k) * 256 + t256] = q2[k];
-    }
-    __syncthreads();
-    if (tid < 2 * TN) {
-      const int which = tid / TN, c = tid % TN;
-      float sum = 0.f;
-      for (int hh = 0; hh < 2; ++hh) {
-        const float* col = qs + (hh * 16 + which * 8 + (c & 7)) * 256 + (c >> 3);
+      for (int k = 0; k < 8; ++k) {
+        qs[k * 512 + tid] = q1[k];
+        qs[(8 + k) * 512 + tid] = q2[k];
+      }
+      __syncthreads();
+      if (tid < 2 * TN) {
+        const int which = tid / TN, c = tid % TN;
+        const float* col = qs + (which * 8 + (c & 7)) * 512 + (c >> 3);
+        float sum = 0.f;
         for (int i = 0; i < PER_IT; ++i) sum += col[i * SEGS];   // fixed order
+        a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = sum;
       }
-      a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = sum;
-    }
-  } else if (a.stats != nullptr) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);  // [2][8 waves][TN]
+    } else if (!JOIN && a.stats != nullptr) {
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(lds + cur);  // [2][8 waves][TN]
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-      if (h == 0) {
-        red[wave * TN + 32 * j + r] = t1;
-        red[8 * TN + wave * TN + 32 * j + r] = t2;
+      for (int j = 0; j < NT; ++j) {
+        const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+        const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+        if (h == 0) {
+          red[wave * TN + 32 * j + r] = t1;
+          red[8 * TN + wave * TN + 32 * j + r] = t2;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * TN) {
+        const int which = tid / TN, c = tid % TN;
+        const float* rr = red + which * 8 * TN + c;
+        a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] =
+            ((rr[0] + rr[TN]) + (rr[2 * TN] + rr[3 * TN])) + ((rr[4 * TN] + rr[5 * TN]) + (rr[6 * TN] + rr[7 * TN]));
       }
     }
-    __syncthreads();
-    if (tid < 2 * TN) {
-      const int which = tid / TN, c = tid % TN;
-      const float* rr = red + which * 8 * TN + c;
-      a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] =
-          ((rr[0] + rr[TN]) + (rr[2 * TN] + rr[3 * TN])) + ((rr[4 * TN] + rr[5 * TN]) + (rr[6 * TN] + rr[7 * TN]));
-    }
+    // the next step's barrier orders these LDS reads before the DMA that will overwrite this buffer
   }
 }
 
@@ -437,11 +509,18 @@ int dt_conv_bf16_dma_launch(ConvBfArgs a, hipStream_t st) {
   a.tiles_y = dt_cdiv(a.Ho, DM_TH);
   a.n_tiles = a.Cout / DM_TN;
   a.P = a.B * a.tiles_x * a.tiles_y;
-  const long grid = (long)a.P * a.n_tiles;
-  if (a.in_scale != nullptr)
-    hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<true>), dim3((unsigned)grid), dim3(512), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  // persistent workgroups: one per CU (157 KB of LDS each), every one walks tiles id, id + grid, ...
+  const int total = a.P * a.n_tiles;
+  const int grid = total < DM_MAX_WGS ? total : DM_MAX_WGS;
+  const bool bnb = a.bnb.y != nullptr, join = a.accumulate != 0;
+  DT_REQUIRE(!bnb || a.stats != nullptr, "conv_bf16_dma: fused BatchNorm-backward sums need the stats buffer");
+  DT_REQUIRE(!(a.in_scale != nullptr && (bnb || join)), "conv_bf16_dma: input transform goes with forward convolutions only");
+  dim3 g((unsigned)grid), blk(512);
+  if (a.in_scale != nullptr) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<true, 0>), g, blk, 0, st, a, total);
+  else if (!bnb && !join) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false, 0>), g, blk, 0, st, a, total);
+  else if (bnb && !join) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false, 1>), g, blk, 0, st, a, total);
+  else if (!bnb && join) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false, 2>), g, blk, 0, st, a, total);
+  else hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false, 3>), g, blk, 0, st, a, total);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

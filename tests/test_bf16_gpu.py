@@ -405,9 +405,32 @@ def test_conv_bf16_dma_kernel_is_bit_identical_to_the_register_staged_kernel(B, 
     finally:
         _set_dma(1)
     a, bq = res[0], res[2]
-    assert torch.equal(a[0], bq[0])
+    # the register-staged variants with 16-channel chunks (narrow layers, 512-pixel tiles) accumulate the same products
+    # in another order: equal up to fp32 summation order there, bit-identical against the 32-channel-chunk variants
+    import ctypes as C
+    from deadtrees_amd import _lib
+    d = ops.conv_desc(B, Hin, Win, C0, C1, mode0, Cout, 3, 1, 1, split, 1 if split else 0)
+    tw, tn, ck, mt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _set_dma(0)
+    _lib.load().dt_conv2d_bf16_config(C.byref(d), C.byref(tw), C.byref(tn), C.byref(ck), C.byref(mt))
+    _set_dma(2)
+    _lib.load().dt_conv2d_bf16_config(C.byref(d), C.byref(tw), C.byref(tn), C.byref(ck), C.byref(mt))
+    assert mt.value == 8                                    # the DMA kernel really ran in mode 2
+    _set_dma(0)
+    _lib.load().dt_conv2d_bf16_config(C.byref(d), C.byref(tw), C.byref(tn), C.byref(ck), C.byref(mt))
+    _set_dma(1)
+    same_order = ck.value == 32
+
+    def check(x, y):
+        if same_order:
+            assert torch.equal(x, y)
+        else:
+            xf, yf = x.float(), y.float()
+            assert float((xf - yf).abs().max()) <= 2.0 ** -7 * float(yf.abs().max())
+            assert float((x != y).float().mean()) < 0.02     # only accumulation-order rounding flips
+    check(a[0], bq[0])
     if a[1] is not None:
-        assert torch.equal(a[1], bq[1])
+        check(a[1], bq[1])
     if a[2] is not None:
         np.testing.assert_allclose(a[2].cpu().numpy(), bq[2].cpu().numpy(), rtol=2e-5, atol=1e-3)
 
