@@ -324,7 +324,7 @@ struct WgCfg {
 static int wg_validate(const dt_conv_desc* d) {
   DT_REQUIRE(d != nullptr, "wgrad: null descriptor");
   DT_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "wgrad: bad sizes");
-  DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && d->stride == 2) ||
+  DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && (d->stride == 1 || d->stride == 2)) ||
                  (d->ksize == 7 && d->stride == 2 && d->C1 == 0 && d->C0 <= 4 && d->mode0 == 0),
              "wgrad: ksize/stride (%d,%d) unsupported", d->ksize, d->stride);
   DT_REQUIRE(d->ksize == 7 || ((d->C0 & 3) == 0 && (d->C1 & 3) == 0), "wgrad: channels must be multiples of 4");
@@ -473,8 +473,10 @@ static int wgrad_impl(const dt_conv_desc* d, const float* src0, const float* src
       rc = c.tw == 32 ? wg_launch<3, 2, 32, 64, 1, 2>(a, grid, st) : wg_launch<3, 2, 16, 64, 1, 2>(a, grid, st);
     else
       rc = c.tw == 32 ? wg_launch<3, 2, 32, 128, 1, 1>(a, grid, st) : wg_launch<3, 2, 16, 128, 1, 1>(a, grid, st);
-  } else {
+  } else if (d->stride == 2) {
     rc = c.tw == 32 ? wg_dispatch<1, 2, 32>(a, c, grid, st) : wg_dispatch<1, 2, 16>(a, c, grid, st);
+  } else {   // 1x1 stride 1: the identity_conv of the ResUnet decoder (resunet/decoder.py:36-38)
+    rc = c.tw == 32 ? wg_dispatch<1, 1, 32>(a, c, grid, st) : wg_dispatch<1, 1, 16>(a, c, grid, st);
   }
   if (rc != DT_OK) return rc;
   const float* slabs = workspace;

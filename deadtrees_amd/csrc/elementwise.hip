@@ -165,6 +165,66 @@ extern "C" int dt_bn_eval_affine(const float* gamma, const float* beta, const fl
   return DT_OK;
 }
 
+// ------------------------------------------------------------------ per-channel sums (bias gradient of a conv)
+// dbias[c] = sum_pixels g[p][c] (convolution_backward's bias gradient; the ResUnet decoder's 1x1 identity_conv and
+// any other biased convolution): row blocks -> partial rows -> fixed-order second stage (fp64 final), no atomics.
+#define CS_RB 256
+__global__ __launch_bounds__(256) void channel_sums_kernel(const f32x4* __restrict__ g, float* __restrict__ part,
+                                                           int64_t n_pix, int C4) {
+  // thread t owns channel quad t % C4 of rows (t / C4) + k * (256 / C4) inside this block's CS_RB rows
+  const int q = threadIdx.x % C4, rl = threadIdx.x / C4, RL = 256 / C4;
+  const int64_t p0 = (int64_t)blockIdx.x * CS_RB;
+  int64_t p1 = p0 + CS_RB;
+  if (p1 > n_pix) p1 = n_pix;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (rl < RL)
+    for (int64_t p = p0 + rl; p < p1; p += RL) s += g[p * C4 + q];
+  __shared__ f32x4 sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < RL; ++k) t += sh[k * C4 + threadIdx.x];   // fixed order
+    reinterpret_cast<f32x4*>(part)[(size_t)blockIdx.x * C4 + threadIdx.x] = t;
+  }
+}
+
+__global__ void channel_sums_final_kernel(const float* __restrict__ part, int P, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)part[(size_t)p * C + c];
+    out[c] = (float)s;
+  }
+}
+
+extern "C" int64_t dt_channel_sums_workspace(int64_t n_pix, int C) {
+  const int P = dt_cdiv(n_pix, CS_RB);
+  const int P2 = dt_reduce_rows_out(P, 64);
+  return ((int64_t)P + P2) * C;
+}
+
+extern "C" int dt_channel_sums(const float* g, float* workspace, int64_t n_pix, int C, float* out, void* stream) {
+  DT_REQUIRE(g && workspace && out && n_pix > 0 && C > 0, "channel_sums: bad args");
+  DT_REQUIRE((C & 3) == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "channel_sums: C/4 must divide 256 (C=%d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int P = dt_cdiv(n_pix, CS_RB);
+  hipLaunchKernelGGL(channel_sums_kernel, dim3(P), dim3(256), 0, st, (const f32x4*)g, workspace, n_pix, C / 4);
+  DT_LAUNCH_CHECK();
+  const float* rows = workspace;
+  int rowsP = P;
+  if (P > 64) {
+    float* stage = workspace + (size_t)P * C;
+    int rc = dt_reduce_rows_launch(workspace, stage, 1, P, C, 64, st);
+    if (rc != DT_OK) return rc;
+    rows = stage;
+    rowsP = dt_reduce_rows_out(P, 64);
+  }
+  hipLaunchKernelGGL(channel_sums_final_kernel, dim3(dt_cdiv(C, 256)), dim3(256), 0, st, rows, rowsP, C, out);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ BN apply (+residual) (+ReLU)
 __global__ __launch_bounds__(256) void bn_act_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
                                                      const float* __restrict__ shift,
@@ -193,12 +253,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const f32x4* __restrict__ y
       }
     }
     f32x4 v = y[i] * sc + sh;
+    if (relu == 2) {   // ReLU on the main branch only, residual added after it (ResUnet decoder block)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+    }
     if (res) {
       f32x4 rv = res[i];
       if (rscale) rv = rv * rsc + rsh;
       v += rv;
     }
-    if (relu) {
+    if (relu == 1) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];   // NaN stays NaN, like torch.relu
     }

@@ -84,7 +84,7 @@ def create_combined_batch(batch: Dict[str, Any]):
     return img, mask, distmap, lu, stats
 
 
-_SUPPORTED_ELSEWHERE = ("unetplusplus", "unet++", "resunet", "resunetplusplus", "resunet++",
+_SUPPORTED_ELSEWHERE = ("unetplusplus", "unet++", "resunetplusplus", "resunet++",
                         "efficientunetplusplus", "efficientunet++")
 
 
@@ -96,6 +96,9 @@ class SemSegment(_Base):
         architecture = network.architecture.lower().strip()
         if architecture == "unet":
             Model = UNetHIP
+        elif architecture == "resunet":     # the reference's in-tree ResUnet (segmodel.py:66-67): same encoder, residual
+            def Model(**kw):                # decoder blocks + 1x1 head, on the same kernels
+                return UNetHIP(decoder="resunet", **kw)
         elif architecture in _SUPPORTED_ELSEWHERE:
             raise NotImplementedError(
                 f"architecture {architecture!r} exists in the reference but has no MI355X kernels in this build "

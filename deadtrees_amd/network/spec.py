@@ -34,6 +34,12 @@ class ConvSpec:
     b_off: int = 0           # BN beta offset (or conv bias for the head)
     bn_off: int = 0          # offset of this BN's channel block in per-channel workspaces
     index: int = 0
+    layout: str = "hwio"     # flat-buffer layout of the weight: "hwio" (convolution kernels) or "ohwi" (head kernel)
+    sd_k: int = 0            # kernel size in the state_dict when it differs from k (1x1 head held as a 3x3 centre tap)
+
+    @property
+    def state_k(self) -> int:
+        return self.sd_k or self.k
 
 
 @dataclass
@@ -49,12 +55,14 @@ class DecBlockSpec:
     conv2: ConvSpec
     in_ch: int = 0
     skip_ch: int = 0
+    idc: Optional[ConvSpec] = None   # ResUnet: 1x1 identity_conv (with bias) of the block input, added to the output
 
 
 @dataclass
 class UNetSpec:
     in_channels: int
     classes: int
+    decoder_kind: str = "unet"     # "unet" (smp Unet decoder) or "resunet" (reference network/extra/resunet/decoder.py)
     stem: ConvSpec = None
     layers: List[List[BlockSpec]] = field(default_factory=list)
     decoder: List[DecBlockSpec] = field(default_factory=list)
@@ -66,8 +74,10 @@ class UNetSpec:
     buckets: list = field(default_factory=list)  # gradient-ready order: [(name, lo, hi)] ranges of the flat buffer
 
 
-def build_spec(in_channels: int = 3, classes: int = 2) -> UNetSpec:
-    s = UNetSpec(in_channels, classes)
+def build_spec(in_channels: int = 3, classes: int = 2, decoder: str = "unet") -> UNetSpec:
+    if decoder not in ("unet", "resunet"):
+        raise ValueError(f"decoder {decoder!r}: 'unet' or 'resunet'")
+    s = UNetSpec(in_channels, classes, decoder)
     convs: List[ConvSpec] = []
 
     def conv(key, bn_key, cin, cout, k, stride, pad):
@@ -97,8 +107,14 @@ def build_spec(in_channels: int = 3, classes: int = 2) -> UNetSpec:
         p = f"decoder.blocks.{i}"
         c1 = conv(f"{p}.conv1.0.weight", f"{p}.conv1.1", ic + sc, oc, 3, 1, 1)
         c2 = conv(f"{p}.conv2.0.weight", f"{p}.conv2.1", oc, oc, 3, 1, 1)
-        s.decoder.append(DecBlockSpec(c1, c2, ic, sc))
+        idc = conv(f"{p}.identity_conv.weight", None, ic + sc, oc, 1, 1, 0) if decoder == "resunet" else None
+        s.decoder.append(DecBlockSpec(c1, c2, ic, sc, idc))
+    # smp SegmentationHead: 3x3 for smp.Unet; the reference's ResUnet builds it with kernel_size=1
+    # (network/extra/resunet/model.py:89-94) — held as the centre tap of the 3x3 head kernel's weights
     s.head = conv("segmentation_head.0.weight", None, DECODER_CHANNELS[-1], classes, 3, 1, 1)
+    s.head.layout = "ohwi"
+    if decoder == "resunet":
+        s.head.sd_k = 1
 
     off = 0
     bn_off = 0
@@ -108,7 +124,7 @@ def build_spec(in_channels: int = 3, classes: int = 2) -> UNetSpec:
         c.w_size = c.k * c.k * c.cin * c.cout
         c.w_off = off
         off = _align4(off + c.w_size)
-        true += c.w_size
+        true += c.state_k * c.state_k * c.cin * c.cout
         if c.bn_key is not None:
             c.g_off = off
             off = _align4(off + c.cout)
@@ -132,7 +148,7 @@ def build_spec(in_channels: int = 3, classes: int = 2) -> UNetSpec:
         hi = max(_align4(c.b_off + c.cout) for c in cs)
         return lo, hi
 
-    dec_convs = [c for d in s.decoder for c in (d.conv1, d.conv2)] + [s.head]
+    dec_convs = [c for d in s.decoder for c in (d.conv1, d.conv2, d.idc) if c is not None] + [s.head]
     s.buckets.append(("head+decoder",) + rng(dec_convs))
     for li in (3, 2, 1, 0):
         cs = [c for b in s.layers[li] for c in (b.conv1, b.conv2, b.down) if c is not None]
@@ -146,7 +162,7 @@ def smp_param_shapes(spec: UNetSpec):
     """{smp_key: shape} for every tensor of the smp state_dict (params and BN buffers)."""
     out = {}
     for c in spec.convs:
-        out[c.key] = (c.cout, c.cin, c.k, c.k)
+        out[c.key] = (c.cout, c.cin, c.state_k, c.state_k)
         if c.bn_key is not None:
             for n in ("weight", "bias", "running_mean", "running_var"):
                 out[f"{c.bn_key}.{n}"] = (c.cout,)

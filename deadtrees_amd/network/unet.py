@@ -163,12 +163,21 @@ class UNetEngine:
         return y, Ho, Wo, (scale, shift)
 
     def _bn_act(self, y, ss, res=None, res_ss=None, relu=True, out=None):
+        """relu: True/1 = ReLU after the residual add, 2 = ReLU on the main branch only (ResUnet decoder), 0 = none"""
         B, H, W, Cc = y.shape
         z = torch.empty_like(y) if out is None else out
         _lib.check(self.lib.dt_bn_act(_p(y), _p(ss[0]), _p(ss[1]), _p(res),
                                       _p(res_ss[0]) if res_ss else None, _p(res_ss[1]) if res_ss else None,
-                                      _p(z), B * H * W, Cc, 1 if relu else 0, _stream()), "dt_bn_act")
+                                      _p(z), B * H * W, Cc, int(relu), _stream()), "dt_bn_act")
         return z
+
+    def _const_vec(self, value: float, n: int, device) -> torch.Tensor:
+        key = f"const_{value}"
+        t = self._ws.get(key)
+        if t is None or t.numel() < n or t.device != device:
+            t = torch.full((max(n, 512),), float(value), dtype=torch.float32, device=device)
+            self._ws[key] = t
+        return t[:n]
 
     # ------------------------------------------------------------------ forward
     def forward(self, x_nchw: torch.Tensor, params: torch.Tensor, bnstate: torch.Tensor, training: bool,
@@ -236,6 +245,25 @@ class UNetEngine:
         for i, blk in enumerate(sp.decoder):
             skip = skips[i]
             Hin, Win = 2 * dh, 2 * dw
+            if sp.decoder_kind == "resunet":
+                # reference network/extra/resunet/decoder.py:40-52: conv1 -> conv2 (conv-BN-ReLU each, extra/modules.py)
+                # plus the 1x1 identity_conv (with bias) of the up-sampled + concatenated input; no activation after
+                # the sum.  The block output is a real tensor (the next block and the head read it).
+                y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training,
+                                                save_stats=save)
+                y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
+                                                in_ss=ss1, save_stats=save)
+                ic = blk.idc
+                C0, C1 = d.shape[-1], (0 if skip is None else skip.shape[-1])
+                idesc = self._desc(B, Hin, Win, C0, C1, 1, Hin, Win, ic.cout, 1, 1, 0)
+                idy = torch.empty((B, Hin, Win, ic.cout), dtype=torch.float32, device=dev)
+                self._conv(idesc, d, skip, params[ic.w_off:ic.w_off + ic.w_size], idy)
+                out = self._bn_act(y2, ss2, res=idy, res_ss=(self._const_vec(1.0, ic.cout, dev),
+                                                             params[ic.b_off:ic.b_off + ic.cout]), relu=2)
+                del idy
+                keep(f"D{i}", x=d, skip=skip, y1=y1, y2=y2, H=h1, W=w1)
+                d, dh, dw, d_ss = out, h2, w2, None
+                continue
             y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training,
                                             in_ss=d_ss, save_stats=save)
             y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
@@ -278,7 +306,7 @@ class UNetEngine:
         if tab is None:
             rows, tiles = [], 0
             for c in self.spec.convs:
-                if c is self.spec.stem or c.bn_key is None:
+                if c is self.spec.stem or c is self.spec.head:
                     continue
                 rows.append([c.w_off, c.k * c.k, c.cin, c.cout, tiles])
                 tiles += c.k * c.k * ((c.cin + 31) // 32) * ((c.cout + 31) // 32)
@@ -402,6 +430,8 @@ class UNetEngine:
                           want_argmax: Optional[str] = None):
         """eval-mode forward with bf16 activations/weights and fp32 accumulation (stem and head stay fp32)."""
         sp, lib = self.spec, self.lib
+        if sp.decoder_kind != "unet":
+            raise NotImplementedError("the bf16 path is built for the unet decoder only")
         if x_nchw.dim() != 4 or x_nchw.shape[1] != sp.in_channels:
             raise RuntimeError(f"expected input [B,{sp.in_channels},H,W], got {tuple(x_nchw.shape)}")
         B, Cin, H, W = x_nchw.shape
@@ -488,6 +518,8 @@ class UNetEngine:
         """training-mode forward with bf16 activations / weights, fp32 accumulation, fp32 BatchNorm statistics
         (taken from the accumulators), fp32 master parameters.  Stem and head run in fp32."""
         sp, lib = self.spec, self.lib
+        if sp.decoder_kind != "unet":
+            raise NotImplementedError("the bf16 path is built for the unet decoder only")
         B, Cin, H, W = x_nchw.shape
         if H % 32 or W % 32 or Cin != sp.in_channels:
             raise RuntimeError(f"bad input {tuple(x_nchw.shape)}")
@@ -906,6 +938,48 @@ class UNetEngine:
             desc = self._desc(B, Hin, Win, c.cout, 0, 2, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
         self._conv(desc, dy, None, wd, out0, out1, None)
 
+    def _backward_resunet_block(self, blk, d, g, params, grads, bnws, B, Hh, Ww, skip_grads, skip_slot):
+        """reverse of one ResUnet decoder block (forward: see the decoder loop): g = gradient of the block output
+        [B,Hh,Ww,cout] -> returns the gradient of the block's low-resolution input; writes the skip gradient."""
+        lib, dev, st = self.lib, g.device, _stream()
+        ic, cx = blk.idc, blk.in_ch
+        sk = 0 if d["skip"] is None else d["skip"].shape[-1]
+        n_pix = B * Hh * Ww
+        # identity branch: weight gradient over the virtual (up-sampled + concatenated) input, bias gradient = sum g
+        self._wgrad(ic, grads, d["x"], d["skip"], 1, B, Hh, Ww, g)
+        ws = self._buf("chsum_ws", int(lib.dt_channel_sums_workspace(n_pix, ic.cout)), device=dev)
+        _lib.check(lib.dt_channel_sums(_p(g), _p(ws), n_pix, ic.cout, _p(grads[ic.b_off:ic.b_off + ic.cout]), st),
+                   "dt_channel_sums")
+        # main branch: relu(bn2(conv2(relu(bn1(conv1(xin))))))  (both activations virtual: masks from y*scale+shift)
+        dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, None, d["y2"], virtual_act=True)
+        self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+        dz1 = torch.empty_like(d["y1"])
+        red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, d["y1"], bnws) if self._fuse_bn else \
+            self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
+        del dy2
+        dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, d["y1"], virtual_act=True, reduced=red1)
+        del dz1
+        self._wgrad(blk.conv1, grads, d["x"], d["skip"], 1, B, Hh, Ww, dy1)
+        dup = torch.empty((B, Hh, Ww, cx), dtype=torch.float32, device=dev)
+        dup_id = torch.empty_like(dup)
+        if sk:
+            dskip, dskip_id = torch.empty_like(d["skip"]), torch.empty_like(d["skip"])
+            self._dgrad(blk.conv1, params, dy1, B, Hh, Ww, dup, dskip, split=cx)
+            self._dgrad(ic, params, g, B, Hh, Ww, dup_id, dskip_id, split=cx)
+            # dskip += dskip_id (the split data-gradient kernels accumulate into their first output only)
+            one, zero = self._const_vec(1.0, sk, dev), self._const_vec(0.0, sk, dev)
+            self._bn_act(dskip, (one, zero), res=dskip_id, relu=0, out=dskip)
+            skip_grads[skip_slot] = dskip
+            del dskip_id
+        else:
+            self._dgrad(blk.conv1, params, dy1, B, Hh, Ww, dup)
+            self._dgrad(ic, params, g, B, Hh, Ww, dup_id)
+        del dy1
+        gx = torch.empty_like(d["x"])
+        _lib.check(lib.dt_upsample2x_bwd(_p(dup), _p(gx), 0, B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd")
+        _lib.check(lib.dt_upsample2x_bwd(_p(dup_id), _p(gx), 1, B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd")
+        return gx
+
     # ------------------------------------------------------------------ backward
     def backward(self, dlogits: torch.Tensor, params: torch.Tensor, grads: torch.Tensor, saved: Optional[_Saved] = None):
         """Hand-scheduled reverse pass.  Writes every parameter gradient into ``grads`` (flat, same layout
@@ -943,10 +1017,19 @@ class UNetEngine:
         # ---- decoder (reverse)
         skip_grads = [None] * 5  # gradient of feats[0..4] = f1..f5
         g_red = None             # BatchNorm-backward partial sums that already came with g (fused producers)
+        if sp.decoder_kind == "resunet" and hd.sd_k == 1:
+            # the 1x1 head lives in the centre tap of the 3x3 head kernel: the other taps stay zero
+            gw = grads[hd.w_off:hd.w_off + hd.w_size].view(K, 9, hd.cin)
+            gw[:, :4].zero_()
+            gw[:, 5:].zero_()
         for i in range(4, -1, -1):
             blk = sp.decoder[i]
             d = S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
+            if sp.decoder_kind == "resunet":
+                g = self._backward_resunet_block(blk, d, g, params, grads, bnws, B, Hh, Ww, skip_grads, 3 - i)
+                S[f"D{i}"] = None
+                continue
             # conv2 + BN + ReLU (activation stored only for the last block)
             dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"], virtual_act=d["z2"] is None,
                                reduced=g_red)
@@ -1098,15 +1181,20 @@ class UNetHIP(nn.Module):
     encoder_weights=None, in_channels=C, classes=K)`` on MI355X."""
 
     def __init__(self, encoder_name: str = "resnet34", encoder_depth: int = 5, encoder_weights=None,
-                 decoder_channels=(256, 128, 64, 32, 16), in_channels: int = 3, classes: int = 2, **unused):
+                 decoder_channels=(256, 128, 64, 32, 16), in_channels: int = 3, classes: int = 2,
+                 decoder: str = "unet", decoder_use_batchnorm=True, decoder_attention_type=None, **unused):
+        """decoder "unet": smp.Unet; "resunet": the reference's in-tree ResUnet (network/extra/resunet/model.py:57-103 —
+        residual decoder blocks with a 1x1 identity_conv, 1x1 segmentation head), fp32 path."""
         super().__init__()
+        if decoder_use_batchnorm is not True or decoder_attention_type is not None:
+            raise NotImplementedError("only decoder_use_batchnorm=True / decoder_attention_type=None have HIP kernels")
         if encoder_name != "resnet34":
             raise NotImplementedError(f"encoder {encoder_name!r}: only resnet34 has HIP kernels")
         if encoder_depth != 5 or tuple(decoder_channels) != (256, 128, 64, 32, 16):
             raise NotImplementedError("only encoder_depth=5 / decoder_channels=(256,128,64,32,16)")
         if encoder_weights is not None:
             raise NotImplementedError("pretrained encoder weights need a network fetch; load a state_dict instead")
-        self.spec = build_spec(in_channels, classes)
+        self.spec = build_spec(in_channels, classes, decoder)
         self.flat_params = nn.Parameter(torch.zeros(self.spec.n_params, dtype=torch.float32))
         self.register_buffer("bn_state", torch.zeros(2 * self.spec.n_bn_channels, dtype=torch.float32),
                              persistent=False)
@@ -1127,8 +1215,9 @@ class UNetHIP(nn.Module):
         g = torch.Generator().manual_seed(seed) if seed is not None else None
         sd = {}
         for c in self.spec.convs:
-            fan_in = c.cin * c.k * c.k
-            sd[c.key] = torch.randn((c.cout, c.cin, c.k, c.k), generator=g) * (2.0 / fan_in) ** 0.5
+            k = c.state_k
+            fan_in = c.cin * k * k
+            sd[c.key] = torch.randn((c.cout, c.cin, k, k), generator=g) * (2.0 / fan_in) ** 0.5
             if c.bn_key is not None:
                 sd[f"{c.bn_key}.weight"] = torch.ones(c.cout)
                 sd[f"{c.bn_key}.bias"] = torch.zeros(c.cout)
@@ -1157,10 +1246,14 @@ class UNetHIP(nn.Module):
             return t
 
         for c in self.spec.convs:
-            w = get(c.key, (c.cout, c.cin, c.k, c.k))
+            w = get(c.key, (c.cout, c.cin, c.state_k, c.state_k))
             if w is not None:
-                if c.bn_key is not None:
-                    flat[c.w_off:c.w_off + c.w_size] = w.permute(2, 3, 1, 0).reshape(-1)   # HWIO
+                if c.state_k != c.k:     # 1x1 head held as the centre tap of the 3x3 head kernel
+                    full = torch.zeros((c.cout, c.cin, c.k, c.k), dtype=torch.float32)
+                    full[:, :, c.k // 2, c.k // 2] = w[:, :, 0, 0]
+                    w = full
+                if c.layout == "hwio":
+                    flat[c.w_off:c.w_off + c.w_size] = w.permute(2, 3, 1, 0).reshape(-1)
                 else:
                     flat[c.w_off:c.w_off + c.w_size] = w.permute(0, 2, 3, 1).reshape(-1)   # head: OHWI
             if c.bn_key is not None:
@@ -1206,9 +1299,20 @@ class UNetHIP(nn.Module):
                 out[prefix + f"{c.bn_key}.running_var"] = bn[2 * c.bn_off + c.cout:2 * c.bn_off + 2 * c.cout].clone()
                 out[prefix + f"{c.bn_key}.num_batches_tracked"] = nbt[c.index].clone()
             else:
-                out[prefix + c.key] = w.reshape(c.cout, c.k, c.k, c.cin).permute(0, 3, 1, 2).contiguous()
+                out[prefix + c.key] = self._oihw(w, c)
                 out[prefix + c.key.replace(".weight", ".bias")] = flat[c.b_off:c.b_off + c.cout].clone()
         return out
+
+    @staticmethod
+    def _oihw(w_flat: torch.Tensor, c: ConvSpec) -> torch.Tensor:
+        """flat-buffer weight of a convolution without BatchNorm (head, identity_conv) -> torch OIHW, state_dict size"""
+        if c.layout == "hwio":
+            w = w_flat.reshape(c.k, c.k, c.cin, c.cout).permute(3, 2, 0, 1)
+        else:
+            w = w_flat.reshape(c.cout, c.k, c.k, c.cin).permute(0, 3, 1, 2)
+        if c.state_k != c.k:
+            w = w[:, :, c.k // 2:c.k // 2 + 1, c.k // 2:c.k // 2 + 1]
+        return w.contiguous()
 
     # nn.Module protocol: expose smp keys so Lightning checkpoints stay interchangeable with the reference
     def _save_to_state_dict(self, destination, prefix, keep_vars):
@@ -1234,7 +1338,7 @@ class UNetHIP(nn.Module):
                 out[f"{c.bn_key}.weight"] = g[c.g_off:c.g_off + c.cout].clone()
                 out[f"{c.bn_key}.bias"] = g[c.b_off:c.b_off + c.cout].clone()
             else:
-                out[c.key] = w.reshape(c.cout, c.k, c.k, c.cin).permute(0, 3, 1, 2).contiguous()
+                out[c.key] = self._oihw(w, c)
                 out[c.key.replace(".weight", ".bias")] = g[c.b_off:c.b_off + c.cout].clone()
         return out
 

@@ -103,8 +103,9 @@ int dt_bn_eval_affine(const float* gamma, const float* beta, const float* runnin
  * mean = running_mean, invstd = 1/sqrt(running_var + eps) for dt_bn_bwd_reduce / dt_bn_bwd_apply_frozen. */
 int dt_bn_eval_stats(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                      float* invstd, void* stream);
-/* out = act( y*scale[c]+shift[c] + (res ? res*rscale[c]+rshift[c] : 0) ), act = ReLU if relu!=0.
- * rscale/rshift NULL -> identity residual.  n_pix = B*H*W. */
+/* out = act( y*scale[c]+shift[c] + (res ? res*rscale[c]+rshift[c] : 0) ), act = ReLU if relu == 1;
+ * relu == 2: ReLU on the main branch only, out = relu(y*scale+shift) + residual (the ResUnet decoder block,
+ * network/extra/resunet/decoder.py:40-52).  rscale/rshift NULL -> identity residual.  n_pix = B*H*W. */
 int dt_bn_act(const float* y, const float* scale, const float* shift, const float* res,
               const float* rscale, const float* rshift, float* out, int64_t n_pix, int C, int relu,
               void* stream);
@@ -129,6 +130,11 @@ int dt_bn_bwd_apply_frozen(const float* dout, const float* out_act, const float*
                            const float* invstd, const float* gamma, const float* act_scale, const float* act_shift,
                            float* red, int P, float* dgamma, float* dbeta, float* dy, float* dres,
                            int dres_accumulate, int64_t n_pix, int C, void* stream);
+
+/* per-channel sums of g [n_pix][C] -> out[C]: the bias gradient of a biased convolution (ATen convolution_backward's
+ * third output; here the 1x1 identity_conv of the ResUnet decoder).  workspace: dt_channel_sums_workspace floats. */
+int64_t dt_channel_sums_workspace(int64_t n_pix, int C);
+int dt_channel_sums(const float* g, float* workspace, int64_t n_pix, int C, float* out, void* stream);
 
 /* ------------------------------------------------------------------ pooling / resampling (K4,K9 bwd) */
 /* max_pool2d(k=3,s=2,p=1) NHWC; argmax (uint8 window position, first max in scan order like ATen). */

@@ -284,3 +284,37 @@ def test_load_from_checkpoint_is_inert_for_hostile_files_and_reads_pickled_param
     for k, v in ref.state_dict().items():
         if not k.endswith("num_batches_tracked"):
             assert torch.equal(got[k].cpu(), v.detach()), k
+
+
+def test_resunet_architecture_surface_and_reference_import_names(tmp_path, monkeypatch):
+    """architecture "resunet" builds (reference segmodel.py:66-67), its state_dict carries the reference module's
+    names (identity_conv, 1x1 head), the other in-tree architectures still raise NotImplementedError with a reason;
+    the `deadtrees.*` modules the reference's callers import resolve; teardown writes the two CSV files."""
+    import importlib
+    from deadtrees.network.segmodel import SemSegment
+    from deadtrees_amd.utils.config import default_network, default_training
+    from oracle.resunet_ref import make_resunet_oracle
+    m = SemSegment(default_network(architecture="ResUnet"), default_training())
+    ref = make_resunet_oracle(3, 2, seed=1)
+    assert set(m.model.state_dict()) == set(ref.state_dict())
+    assert sum(p.numel() for p in ref.parameters()) == m.model.spec.n_true_params == 24_699_410
+    m.model.load_state_dict(ref.state_dict())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(m.model.state_dict()[k], v), k
+    for arch in ("unet++", "resunet++", "efficientunet++"):
+        with pytest.raises(NotImplementedError):
+            SemSegment(default_network(architecture=arch), default_training())
+    for name in ("deadtrees.network.segmodel", "deadtrees.data.deadtreedata", "deadtrees.deployment.inference",
+                 "deadtrees.deployment.tiler", "deadtrees.loss.losses", "deadtrees.loss.gdl", "deadtrees.loss.gwdl",
+                 "deadtrees.utils.data_handling"):
+        importlib.import_module(name)
+    from deadtrees.deployment.inference import ONNXInference, PyTorchEnsembleInference, PyTorchInference  # noqa: F401
+    from deadtrees.data.deadtreedata import val_transform  # noqa: F401
+    with pytest.raises(ValueError):
+        ONNXInference("model.ckpt")
+    m.stats["train"].update(["a.tif", "a.tif", "b.tif"])
+    m.stats["val"].update(["c.tif"])
+    monkeypatch.chdir(tmp_path)
+    m.teardown()
+    assert (tmp_path / "train_stats.csv").read_text() == "filename,count\na.tif,2\nb.tif,1\n"
+    assert (tmp_path / "val_stats.csv").read_text() == "filename,count\nc.tif,1\n"

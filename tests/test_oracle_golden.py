@@ -101,3 +101,45 @@ def test_unet_ref_shapes_and_keys():
     # K=1 gives the well-known smp parameter count
     from oracle.unet_ref import UNetR34Ref
     assert sum(p.numel() for p in UNetR34Ref(3, 1).parameters()) == 24_436_369
+
+
+def test_resunet_decoder_oracle_against_the_executed_reference(golden_dir):
+    """oracle/resunet_ref.ResUnetDecoderRef against tests/golden/resunet_decoder.npz (the reference's own
+    ResUnetDecoder, executed by oracle/make_golden_resunet.py): output, every parameter gradient, every feature
+    gradient, BatchNorm running statistics — and, with the identity convolutions zeroed, the PLAIN U-Net decoder of
+    oracle/unet_ref.py, which pins its wiring (feature order, nearest x2, cat([x, skip]), channel arithmetic)."""
+    import torch
+    from oracle.resunet_ref import ResUnetDecoderRef
+    from oracle.unet_ref import UnetDecoder
+    z = np.load(os.path.join(golden_dir, "resunet_decoder.npz"))
+    enc_ch, dec_ch = tuple(int(v) for v in z["enc_ch"]), tuple(int(v) for v in z["dec_ch"])
+    dec = ResUnetDecoderRef(enc_ch, dec_ch)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")}
+    assert set(sd) == set(dec.state_dict())                  # same parameter / buffer names as the reference module
+    dec.load_state_dict(sd)
+    dec.train()
+    feats = [None] + [torch.from_numpy(z[f"feat{i}"]).requires_grad_(True) for i in range(1, 6)]
+    out = dec(*feats)
+    np.testing.assert_allclose(out.detach().numpy(), z["out"], rtol=1e-5, atol=1e-5)
+    (out * torch.from_numpy(z["gout"])).sum().backward()
+    for i in range(1, 6):
+        np.testing.assert_allclose(feats[i].grad.numpy(), z[f"dfeat{i}"], rtol=1e-4, atol=1e-5)
+    for k, p in dec.named_parameters():
+        ref = z[f"grad:{k}"]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    for k, v in dec.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), z[f"after:{k}"], rtol=1e-5, atol=1e-6)
+    # plain U-Net decoder = the same weights without the 1x1 residual branch
+    plain = UnetDecoder(enc_ch, dec_ch)
+    psd = {k: v for k, v in sd.items() if "identity_conv" not in k}
+    assert set(psd) == set(plain.state_dict())
+    plain.load_state_dict(psd)
+    plain.train()
+    with torch.no_grad():
+        got = plain(*[None if f is None else f.detach() for f in feats])
+    np.testing.assert_allclose(got.numpy(), z["out_plain"], rtol=1e-5, atol=1e-5)
+    plain.eval()
+    with torch.no_grad():
+        got = plain(*[None if f is None else f.detach() for f in feats])
+    np.testing.assert_allclose(got.numpy(), z["out_plain_eval"], rtol=1e-5, atol=1e-5)

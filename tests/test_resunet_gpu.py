@@ -1,0 +1,103 @@
+"""architecture "resunet" (the reference's in-tree ResUnet, deadtrees/network/segmodel.py:66-67 ->
+network/extra/resunet/{model,decoder}.py) on the HIP kernels, against oracle/resunet_ref.py — whose decoder is pinned
+by the executed reference (tests/golden/resunet_decoder.npz, tests/test_oracle_golden.py)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _pair(C=3, K=2, seed=0):
+    from deadtrees_amd.network.unet import UNetHIP
+    from oracle.resunet_ref import make_resunet_oracle
+    ref = make_resunet_oracle(C, K, seed=seed)
+    m = UNetHIP(in_channels=C, classes=K, decoder="resunet")
+    m.load_state_dict(ref.state_dict())
+    return ref, m.to(DEV)
+
+
+@pytest.mark.parametrize("B,H,W,C,K", [(2, 64, 64, 3, 2), (1, 128, 160, 4, 3)])
+def test_resunet_forward_eval_parity_and_argmax(B, H, W, C, K):
+    from deadtrees_amd.data.synthetic import synth_batch
+    ref, m = _pair(C, K)
+    img, _ = synth_batch(B, H, W, C, K, seed=5)
+    ref.eval()
+    m.eval()
+    with torch.no_grad():
+        want64 = copy.deepcopy(ref).double()(img.double())
+        got = m(img.to(DEV)).cpu()
+    scale, err = float(want64.abs().max()), float((got.double() - want64).abs().max())
+    assert err <= 1e-4 * scale, (err, scale)
+    top2 = want64.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4 * err
+    am = m.predict_classes(img.to(DEV)).cpu()
+    assert torch.equal(am, got.argmax(dim=1)) and torch.equal(am[safe], want64.argmax(dim=1)[safe])
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_resunet_training_step_gradients(mode):
+    """loss and every parameter gradient (incl. the 1x1 identity convolutions, their biases and the 1x1 head) against
+    the fp64 oracle: 1e-4 per tensor with frozen BatchNorm (well conditioned), the fp32-CPU yardstick with batch
+    statistics (see tests/test_model_gpu.py::test_train_step_gradient_parity)."""
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.loss.seg_loss import seg_loss
+    from oracle.train_ref import loss_from_logits
+    ref, m = _pair(3, 2, seed=3)
+    img, mask = synth_batch(2, 128, 128, 3, 2, seed=6)
+    ref64, ref32 = copy.deepcopy(ref).double(), copy.deepcopy(ref)
+    for mod in (ref64, ref32, m):
+        mod.train(mode == "train")
+    logits = m(img.to(DEV))
+    loss, _, _ = seg_loss(logits, mask.to(DEV), None, ("GDICE", "FOCAL"))
+    loss.backward()
+    l64 = ref64(img.double())
+    loss64, _ = loss_from_logits(l64, mask, ("GDICE", "FOCAL"))
+    loss64.backward()
+    loss32, _ = loss_from_logits(ref32(img), mask, ("GDICE", "FOCAL"))
+    loss32.backward()
+    assert float(loss.detach()) == pytest.approx(float(loss64.detach()), rel=2e-5)
+    grads = m.smp_grad_dict()
+    g32 = {k: p.grad for k, p in ref32.named_parameters()}
+    assert set(grads) == {k for k, _ in ref64.named_parameters()}
+    gscale = max(float(p.grad.norm()) for p in ref64.parameters())
+    worst = (0.0, "")
+    for k, p in ref64.named_parameters():
+        n = float(p.grad.norm())
+        e = float((grads[k].double() - p.grad).norm())
+        e32 = float((g32[k].double() - p.grad).norm())
+        worst = max(worst, (e / (n + 1e-30), k))
+        if mode == "eval":
+            assert e <= 1e-4 * n + 1e-7 * gscale, (k, e / n)
+        else:
+            assert e <= 4.0 * e32 + 1e-4 * n + 1e-7 * gscale, (k, e / n, e32 / n)
+    print(f"[resunet {mode}] worst per-tensor gradient rel-L2 vs fp64 oracle: {worst[0]:.2e} ({worst[1]})")
+    if mode == "train":
+        sd_ref, sd = ref32.state_dict(), m.state_dict()
+        for k in sd_ref:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                np.testing.assert_allclose(sd[k].cpu().numpy(), sd_ref[k].numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+
+
+def test_resunet_trains_through_semsegment_and_hiptrainer():
+    """SemSegment(architecture="resunet") builds the model; HipTrainer steps it (loss falls, head stays 1x1)."""
+    from deadtrees.network.segmodel import SemSegment
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.trainer import HipTrainer
+    from deadtrees_amd.utils.config import default_network, default_training
+    model = SemSegment(default_network(architecture="resunet"), default_training()).to(DEV)
+    assert model.model.spec.decoder_kind == "resunet"
+    assert tuple(model.model.state_dict()["segmentation_head.0.weight"].shape) == (2, 16, 1, 1)
+    img, mask = synth_batch(4, 64, 64, 3, 2, seed=9)
+    img[:, 0] += 2.5 * mask.float()
+    tr = HipTrainer(model.model, lr=1e-3)
+    losses = [float(tr.step(img.to(DEV), mask.to(DEV))) for _ in range(12)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    hd = model.model.spec.head
+    w = model.model.flat_params.detach()[hd.w_off:hd.w_off + hd.w_size].view(2, 9, 16)
+    assert float(w[:, :4].abs().max()) == 0.0 and float(w[:, 5:].abs().max()) == 0.0      # off-centre taps stay zero
+    with pytest.raises(NotImplementedError):
+        HipTrainer(model.model, precision="bf16").step(img.to(DEV), mask.to(DEV))
