@@ -82,4 +82,10 @@ def make_resunet_oracle(in_channels: int = 3, classes: int = 2, seed: int = 0) -
                 mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
                 mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=g))
                 mod.running_var.copy_(1.0 + 0.2 * torch.rand(mod.running_var.shape, generator=g))
+        # He-initialised residual branches without a normalisation after the sum make the activations grow block by
+        # block (logits of several thousand: a saturated softmax, an ill-conditioned loss gradient).  Parity tests
+        # want O(1..10) logits: damp the 1x1 identity convolutions and the head.
+        for blk in m.decoder.blocks:
+            blk.identity_conv.weight.mul_(0.25)
+        m.segmentation_head[0].weight.mul_(0.1)
     return m
