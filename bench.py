@@ -340,6 +340,40 @@ def infer_bench(args, model, dev, world, rank, distributed):
                 host_out[k].copy_(o, non_blocking=True)
             torch.cuda.synchronize()
             pcie = B * n / (time.perf_counter() - t1)
+    # BASELINE configs[4] end to end (scripts/inference.py:80-115 per ortho tile): a synthetic (4, 2048, 2048) uint8
+    # raster -> block split (64 sub-tiles of 256x256 or 16 of 512x512) -> uint8 H2D -> normalise + forward + argmax on the
+    # device -> uint8 D2H -> block merge.  Host work (split / merge, pageable copies) included; rank r takes ortho
+    # tiles r, r + N, ... of the queue (no collective)
+    tiler = None
+    if S in (256, 512):
+        import numpy as np
+        from deadtrees_amd.deployment.tiler import infer_tile
+
+        class _U8:
+            def run_u8(self, tiles_u8, device=None):
+                x = ops.normalize_u8(tiles_u8.to(dev, non_blocking=True), MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
+                return model.predict_classes(x, dtype="uint8", precision=args.precision)
+
+        ortho = np.random.default_rng(7 + rank).integers(0, 256, (4, 2048, 2048), dtype=np.uint8)
+        infer_tile(_U8(), ortho, subtile=S, batch_size=64, device=str(dev))          # warm-up
+        n_ortho = 3
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for _ in range(n_ortho):
+            merged = infer_tile(_U8(), ortho, subtile=S, batch_size=64, device=str(dev))
+        torch.cuda.synchronize()
+        dt2 = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(dt2, op=dist.ReduceOp.MAX)
+        per_ortho = float(dt2) / n_ortho
+        km2_ortho = (2048 * 0.20002 / 1000.0) ** 2       # 0.1678 km^2 per 2048^2 source tile
+        tiler = {"ms_per_2048_ortho_tile": round(1e3 * per_ortho, 2),
+                 "subtiles_per_s": round(world * (2048 // S) ** 2 / per_ortho, 1),
+                 "km2_per_hour": round(world * km2_ortho / per_ortho * 3600.0, 1),
+                 "what": "split + uint8 H2D + normalise/forward/argmax + uint8 D2H + merge, pageable host arrays",
+                 "foreground_fraction": round(float(merged.mean()), 4)}
     tiles_s = B * world * args.steps / wall
     km2_per_tile = (S * 0.20002 / 1000.0) ** 2          # pixel 0.20002 m (scripts/computestats_inference.py:57-59)
     fwd_flop = 62.59e9 * (S / 512.0) ** 2
@@ -352,6 +386,7 @@ def infer_bench(args, model, dev, world, rank, distributed):
            "km2_per_hour": round(tiles_s * km2_per_tile * 3600.0, 1),
            "whole_net": {"tflops": round(tiles_s / world * fwd_flop / 1e12, 2),
                          "mfma_frac": round(tiles_s / world * fwd_flop / 1e12 / PEAK_FP32_TFLOPS, 4)},
+           "tiler_inclusive": tiler,
            "foreground_pixels": int(out.sum()), "hip_graph": use_graph,
            "pcie_inclusive_tiles_per_s_per_gpu": None if pcie is None else round(pcie, 1)}
     if rank == 0:

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
   const int t = (int)blockIdx.x - row[4];
   const int cob = (Cout + 31) / 32, cib = (Cin + 31) / 32;
   const int tap = t / (cib * cob), ci0 = ((t / cob) % cib) * 32, co0 = (t % cob) * 32;
-  const bool flip = mode != 1, transpose = mode != 2;
+  const bool flip = mode == 0 || mode == 2 || mode == 4, transpose = mode == 0 || mode == 1 || mode == 3;
   const float* w = params + w_off + (size_t)(flip ? taps - 1 - tap : tap) * Cin * Cout;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8) {
@@ -701,6 +701,19 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
   }
   __syncthreads();
   const size_t obase = (size_t)w_off + (size_t)tap * Cin * Cout;
+  if (mode >= 3) {
+    // chunked images for the LDS-DMA kernels (conv_bf16_dma.hip): [tap][K/32][N][32] — the 64 output rows x 32 input
+    // channels one workgroup stages per (tap, chunk) are ONE contiguous 4 KiB block, so every 1 KiB DMA piece reads
+    // whole cache lines (the [tap][N][K] image gives 64-byte fragments of 16 different lines per piece)
+    if ((Cin & 31) || (Cout & 31)) return;
+    for (int i = ty; i < 32; i += 8) {
+      if (mode == 3)   // forward: N = Cout, K = Cin; row co0 + i holds the 32 input channels ci0 .. ci0 + 31
+        reinterpret_cast<__bf16*>(out)[obase + ((size_t)(ci0 >> 5) * Cout + co0 + i) * 32 + tx] = (__bf16)tile[tx][i];
+      else             // data gradient: N = Cin, K = Cout; row ci0 + i holds the 32 channels co0 .. co0 + 31
+        reinterpret_cast<__bf16*>(out)[obase + ((size_t)(co0 >> 5) * Cin + ci0 + i) * 32 + tx] = (__bf16)tile[i][tx];
+    }
+    return;
+  }
   for (int i = ty; i < 32; i += 8) {
     if (transpose) {
       const int co = co0 + i, ci = ci0 + tx;
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
 
 extern "C" int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles,
                                 int mode, void* stream) {
-  DT_REQUIRE(params && out && table && n_layers > 0 && total_tiles > 0 && mode >= 0 && mode <= 2,
+  DT_REQUIRE(params && out && table && n_layers > 0 && total_tiles > 0 && mode >= 0 && mode <= 4,
              "weight_images: bad args");
   hipLaunchKernelGGL(weight_images_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, params, out,
                      table, n_layers, mode);

@@ -346,22 +346,32 @@ class UNetEngine:
         self._stem_s2d = None
         return P, sbuf
 
-    def _bf16_weights(self, params: torch.Tensor, dgrad: bool = False):
+    def _bf16_weights(self, params: torch.Tensor, dgrad: bool = False, chunked: bool = False):
         """bf16 images of every conv weight except stem and head: [tap][Cout][Cin] for the forward convs, or the
         data-gradient image (HWIO with reversed taps).  Repacked when the flat parameter buffer changed: torch's
         version counter catches torch-side writes, ``self.weights_dirty`` the fused optimiser's raw writes."""
-        name = "bf16_wd" if dgrad else "bf16_w"
+        name = ("bf16_wd" if dgrad else "bf16_w") + ("c" if chunked else "")   # chunked: [tap][K/32][N][32] (DMA kernels)
         key = (params.data_ptr(), params._version, self._weights_epoch)
         if self._ws.get(name + "_key") == key:
             return self._ws[name]
         buf = self._ws.get(name)
         if buf is None or buf.device != params.device:
             buf = torch.empty(self.spec.n_params, dtype=torch.bfloat16, device=params.device)
-        self._weight_images(params, buf, 2 if dgrad else 1)     # every layer's image in one launch
+        mode = (4 if dgrad else 3) if chunked else (2 if dgrad else 1)
+        self._weight_images(params, buf, mode)     # every layer's image in one launch
         self._ws[name + "_key"], self._ws[name] = key, buf
         return buf
 
-    def _conv_bf16(self, desc, src0, src1, w, out0, out1, stats, in_ss, what="dt_conv2d_bf16"):
+    def _uses_dma_kernel(self, desc) -> bool:
+        """the LDS-DMA staged kernels (reported as mt == 8) read the CHUNKED weight images"""
+        tw, tn, ck, mt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        if self.lib.dt_conv2d_bf16_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck), C.byref(mt)) != 0:
+            return False
+        return mt.value == 8
+
+    def _conv_bf16(self, desc, src0, src1, w, out0, out1, stats, in_ss, what="dt_conv2d_bf16", w_chunked=None):
+        if w_chunked is not None and self._uses_dma_kernel(desc):
+            w = w_chunked
         prof = self.profile
         if prof is not None:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -440,6 +450,7 @@ class UNetEngine:
         dev = x_nchw.device
         st = _stream()
         wb = self._bf16_weights(params)
+        wbc = self._bf16_weights(params, chunked=True)
         bnws = self._buf("bnws", 4 * sp.n_bn_channels, device=dev)
         bf = torch.bfloat16
 
@@ -458,7 +469,8 @@ class UNetEngine:
             C1 = 0 if src1 is None else src1.shape[-1]
             desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
             y = torch.empty((B, Ho, Wo, c.cout), dtype=bf, device=dev)
-            self._conv_bf16(desc, src0, src1, wb[c.w_off:c.w_off + c.w_size], y, None, None, in_ss)
+            self._conv_bf16(desc, src0, src1, wb[c.w_off:c.w_off + c.w_size], y, None, None, in_ss,
+                            w_chunked=wbc[c.w_off:c.w_off + c.w_size])
             return y, Ho, Wo, affine(c)
 
         def bn_act(y, ss, res=None, res_ss=None, y_f32=False):
@@ -525,6 +537,7 @@ class UNetEngine:
             raise RuntimeError(f"bad input {tuple(x_nchw.shape)}")
         dev, st, bf = x_nchw.device, _stream(), torch.bfloat16
         wb = self._bf16_weights(params)
+        wbc = self._bf16_weights(params, chunked=True)
         sv = _Saved()
         bnws = torch.empty(4 * sp.n_bn_channels, dtype=torch.float32, device=dev)
         sv.d["bnws"] = bnws
@@ -552,7 +565,8 @@ class UNetEngine:
                 raise RuntimeError(lib.dt_last_error().decode())
             stats = self._buf("bn_stats", lib.dt_bn_stats_floats(P, c.cout), device=dev)
             y = torch.empty((B, Ho, Wo, c.cout), dtype=bf, device=dev)
-            self._conv_bf16(desc, src0, src1, wb[c.w_off:c.w_off + c.w_size], y, None, stats, in_ss)
+            self._conv_bf16(desc, src0, src1, wb[c.w_off:c.w_off + c.w_size], y, None, stats, in_ss,
+                            w_chunked=wbc[c.w_off:c.w_off + c.w_size])
             return y, Ho, Wo, finalize(c, stats, P, B * Ho * Wo)
 
         def bn_act(y, ss, res=None, res_ss=None, y_f32=False):
@@ -632,6 +646,7 @@ class UNetEngine:
         B, bnws = S["B"], S["bnws"]
         dev, st, bf = dlogits.device, _stream(), torch.bfloat16
         wbd = self._bf16_weights(params, dgrad=True)
+        wbdc = self._bf16_weights(params, dgrad=True, chunked=True)
         nb = sp.n_bn_channels
 
         def bn_bwd(c, dout, out_act, y, dres=None, dres_acc=False, virtual_act=False, reduced=None):
@@ -682,7 +697,8 @@ class UNetEngine:
             asc, ash = self._ss(bn_conv, bnws) if act is None else (None, None)
             fuse = _lib.BnBwdFuse(_p(y), _p(bnws[bn_conv.bn_off:bn_conv.bn_off + Cq]),
                                   _p(bnws[nb + bn_conv.bn_off:nb + bn_conv.bn_off + Cq]), _p(asc), _p(ash), _p(act))
-            _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(desc), _p(dy), _p(wbd[c.w_off:c.w_off + c.w_size]), _p(out0),
+            wsel = wbdc if self._uses_dma_kernel(desc) else wbd
+            _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(desc), _p(dy), _p(wsel[c.w_off:c.w_off + c.w_size]), _p(out0),
                                                  _p(red), C.byref(fuse), _stream()), "dt_conv2d_bf16_bn_bwd")
             return red, P
 
@@ -694,7 +710,7 @@ class UNetEngine:
             else:
                 desc = self._desc(B, Hin, Win, c.cout, 0, 2, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
             self._conv_bf16(desc, dy, None, wbd[c.w_off:c.w_off + c.w_size], out0, out1, None, None,
-                            "dt_conv2d_bf16(dgrad)")
+                            "dt_conv2d_bf16(dgrad)", w_chunked=wbdc[c.w_off:c.w_off + c.w_size])
 
         # ---- head (fp32) -> bf16 gradient of the last decoder activation
         hd, hsv = sp.head, S["head"]

@@ -243,11 +243,21 @@ def conv2d_bf16(src0, w_packed, k, stride, pad, cout, src1=None, mode0=0, split=
         if P <= 0:
             raise RuntimeError(lib.dt_last_error().decode())
         stats = torch.empty(lib.dt_bn_stats_floats(P, cout), dtype=torch.float32, device=dev)
+    w_packed = _dma_image(d, w_packed, k, C0 + C1, cout)
     _lib.check(lib.dt_conv2d_bf16(C.byref(d), _p(src0), _p(src1), _p(w_packed), _p(out0), _p(out1), _p(stats),
                                   _p(in_scale), _p(in_shift), _st()), "dt_conv2d_bf16")
     if stats is not None:
         stats = stats[:2 * P * cout].view(2, P, cout)
     return out0, out1, stats
+
+
+def _dma_image(d, w_packed, k, cin, cout):
+    """the LDS-DMA staged kernels (dt_conv2d_bf16_config reports mt == 8) read the weights in the chunked layout
+    [tap][Cin/32][Cout][32] (dt_weight_images modes 3 / 4); this test-level wrapper re-arranges a [tap][Cout][Cin] image"""
+    tw, tn, ck, mt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if _lib.load().dt_conv2d_bf16_config(C.byref(d), C.byref(tw), C.byref(tn), C.byref(ck), C.byref(mt)) != 0 or mt.value != 8:
+        return w_packed
+    return w_packed.view(k * k, cout, cin // 32, 32).permute(0, 2, 1, 3).contiguous()
 
 
 def pack_weights_bf16(w_hwio, dgrad=False):
@@ -344,6 +354,7 @@ def conv2d_bf16_bn_bwd(src0, w_packed, cout, y, mean, invstd, act_scale=None, ac
     out = join_into if join_into is not None else torch.empty((B, H, W, cout), dtype=torch.bfloat16,
                                                               device=src0.device)
     fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift), _p(act))
+    w_packed = _dma_image(d, w_packed, 3, C0, cout)
     _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(d), _p(src0), _p(w_packed), _p(out), _p(red), C.byref(fuse), _st()),
                "dt_conv2d_bf16_bn_bwd")
     return out, red[:2 * P * cout].view(2, P, cout)

@@ -321,7 +321,9 @@ int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C
  * [n_layers][5] = (w_off, taps, Cin, Cout, first_tile) on the DEVICE, first_tile = running sum of
  * taps*ceil(Cin/32)*ceil(Cout/32); total_tiles = that sum over all layers.  The image of layer l lands at out + w_off
  * (in elements of the output type).  mode 0 = dt_weight_flip_transpose (fp32), 1 = dt_pack_weights_bf16,
- * 2 = dt_pack_dgrad_weights_bf16. */
+ * 2 = dt_pack_dgrad_weights_bf16; 3 / 4 = the forward / data-gradient bf16 images in the chunked layout
+ * [tap][K/32][N][32] that the LDS-DMA staged kernels read (dt_conv2d_bf16 reports them with mt == 8 in
+ * dt_conv2d_bf16_config: pass THAT image to such a launch); layers with K or N not a multiple of 32 are skipped. */
 int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles, int mode,
                      void* stream);
 
@@ -380,7 +382,9 @@ int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, co
 /* Kernel-selection switches (host side, process wide; every choice computes the same values):
  *   "bf16_dma": 0 = register-staged bf16 convolutions only, 1 (default) = the LDS-DMA staged 512-pixel kernel where
  *               its tiles fill the chip, 2 = wherever its shape conditions hold.  Also read from the environment
- *               variable DT_BF16_DMA at first use. */
+ *               variable DT_BF16_DMA at first use.
+ *   "bf16_ws":  1 = plain-store launches of that kernel use its wave-specialised form (4 compute + 4 producer waves;
+ *               measured slower, kept for experiments), 0 (default) = all eight waves do both.  Env: DT_BF16_WS. */
 int dt_set_option(const char* name, int value);
 
 #ifdef __cplusplus
