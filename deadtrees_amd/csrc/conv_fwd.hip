@@ -426,18 +426,10 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
     };
     issue_loads(0);
     for (int c0 = 0; c0 < Cin; c0 += CK) {
-#ifdef DT_EXP_NOFILL
-      if (c0 == 0) {
-        __syncthreads();
-        write_lds(c0);
-        __syncthreads();
-      }
-#else
       __syncthreads();   // every wave is done reading the previous chunk
       write_lds(c0);
       __syncthreads();
       if (c0 + CK < Cin) issue_loads(c0 + CK);
-#endif
       if constexpr (ZI)
         mma_chunk_zi<KS, TN, CK, G::PLANE, G::HALO_W>(lds_in, lds_w, abase, bbase, acc, wave, a.pad);
       else

@@ -361,8 +361,8 @@ static WgCfg wg_cfg(const dt_conv_desc* d) {
     c.tw = d->Wo > 16 ? 32 : 16;
     const bool ci_wide = Cin > 32, co_wide = d->Cout > 32;
     if (d->stride == 2 && d->ksize == 3) {
-      if (co_wide) { c.wci = 1; c.wco = 2; c.wk = 2; } else { c.wci = 1; c.wco = 1; c.wk = 4; }
-      c.tpx = co_wide ? 64 : 128;
+      // one arrangement for stride 2 (every such conv of the net has Cout >= 128); a narrower Cout is masked
+      c.wci = 1; c.wco = 2; c.wk = 2; c.tpx = 64;
     } else if (ci_wide && co_wide) { c.wci = 2; c.wco = 2; c.wk = 1; c.tpx = 64; }
     else if (!ci_wide && co_wide) { c.wci = 1; c.wco = 2; c.wk = 2; c.tpx = 128; }
     else if (ci_wide && !co_wide) { c.wci = 2; c.wco = 1; c.wk = 2; c.tpx = 128; }
@@ -468,11 +468,8 @@ static int wgrad_impl(const dt_conv_desc* d, const float* src0, const float* src
   } else if (d->ksize == 3 && d->stride == 1) {
     rc = c.tw == 32 ? wg_dispatch<3, 1, 32>(a, c, grid, st) : wg_dispatch<3, 1, 16>(a, c, grid, st);
   } else if (d->ksize == 3 && d->stride == 2) {
-    // only the (1,2,k2,tpx64) and (1,1,k4,tpx128) arrangements are generated for stride 2
-    if (c.wco == 2)
-      rc = c.tw == 32 ? wg_launch<3, 2, 32, 64, 1, 2>(a, grid, st) : wg_launch<3, 2, 16, 64, 1, 2>(a, grid, st);
-    else
-      rc = c.tw == 32 ? wg_launch<3, 2, 32, 128, 1, 1>(a, grid, st) : wg_launch<3, 2, 16, 128, 1, 1>(a, grid, st);
+    // only the (1,2,k2,tpx64) arrangement is generated for stride 2
+    rc = c.tw == 32 ? wg_launch<3, 2, 32, 64, 1, 2>(a, grid, st) : wg_launch<3, 2, 16, 64, 1, 2>(a, grid, st);
   } else if (d->stride == 2) {
     rc = c.tw == 32 ? wg_dispatch<1, 2, 32>(a, c, grid, st) : wg_dispatch<1, 2, 16>(a, c, grid, st);
   } else {   // 1x1 stride 1: the identity_conv of the ResUnet decoder (resunet/decoder.py:36-38)
