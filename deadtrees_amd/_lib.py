@@ -49,6 +49,10 @@ SIGNATURES = {
     "dt_conv2d_config": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dt_conv2d_uses_zi": (C.c_int, [_P]),
     "dt_weight_flip_transpose": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_conv2d_winograd_supported": (C.c_int, [_P]),
+    "dt_conv2d_winograd_stat_rows": (C.c_int, [_P]),
+    "dt_winograd_weights": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f]),
+    "dt_conv2d_winograd": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),
     "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),
     "dt_bn_stats_floats": (I64, [C.c_int, C.c_int]),

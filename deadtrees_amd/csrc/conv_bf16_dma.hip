@@ -50,11 +50,6 @@ __device__ __forceinline__ void dm_dma16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((dm_gptr)g, (dm_lptr)l, 16, 0, 0);
 }
 
-// Workgroup barrier WITHOUT the fences of __syncthreads(): those make hipcc drain vmcnt before every barrier, i.e.
-// wait for the producer waves' in-flight global stores.  The memory clobber keeps the compiler from moving LDS
-// accesses across it; every wave waits for its own LDS writes / DMA pieces explicitly before it arrives.
-__device__ __forceinline__ void ws_barrier() { asm volatile("s_barrier" ::: "memory"); }
-
 // EPI selects the epilogue at compile time (register pressure: the persistent loop keeps the accumulators, the next
 // tile's staging context and the epilogue's state live together): 0 plain store (+ BatchNorm statistics, split
 // outputs), 1 plain store + fused BatchNorm-backward sums (virtual activation), 2 gradient join (fp32 staging, split
@@ -474,412 +469,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant (plain-store epilogues, EPI 0 / 1): waves 0-3 only multiply, waves 4-7 only move data.
-// Measured on the kernel above (ablation builds): its MFMA loop alone sustains 1.40-1.46 PFLOP/s, but
-// every wave also issues its share of the 75 DMA pieces per chunk (~0.8 us per chunk of matrix-pipe idle time) and the
-// whole workgroup stops for the epilogue (4-5 us per 512-pixel tile: 45 % of a 64-channel layer's time).  Here
-//   * compute wave w owns output rows 4w..4w+3 (128 pixels x 64 channels, 8 accumulator tiles): per (kw, k-half) it
-//     loads the 6 input rows it needs once and reuses them for the 3 kernel rows -> 0.5 LDS fragment reads per MFMA
-//     (was 1.0), nothing else in its instruction stream;
-//   * producer waves issue all DMA pieces (or the register-staged, BatchNorm+ReLU-transformed input) of chunk s+1
-//     while chunk s is multiplied, wait for them to land, and meet the compute waves at ONE barrier per chunk;
-//   * at a tile boundary the compute waves drop their accumulators (bf16) and BatchNorm partial sums into the operand
-//     buffer they have just finished with, pass a second barrier and carry on with the next tile's first chunk; the
-//     producers then move that image to HBM (16-byte stores, fused BatchNorm-backward sums) and only afterwards stage
-//     the following chunk into the same buffer: the epilogue runs beside the next tile's MFMAs.
-// One compute and one producer wave share each SIMD (a workgroup's waves are dealt to the SIMDs cyclically).
-//
-// MEASURED (same box, B=64, scripts/bench_conv.py, DT_BF16_WS=1 vs 0): 64->64 @128^2 404 vs 667 TFLOP/s, 128->128 @64^2
-// 608 vs 796, 256->256 @32^2 817 vs 915, 768->256 @32^2 1118 vs 1113.  With few chunks per tile the chain
-// drop -> flush -> store drain -> stage of a tile boundary (~6 us on the producers) is longer than the MFMA step it
-// should hide behind (2.4 us), and in steady state (24 chunks per tile) the step time is the same 4.3 us: the DMA's LDS
-// writes and the fragment reads contend for the LDS whoever issues them.  The symmetric kernel above therefore stays
-// the default; this form is kept selectable (option "bf16_ws") and parity-tested because it is the natural starting
-// point for a 3-buffer / resident-weights variant.
-template <bool TF, int EPI>
-__global__ __launch_bounds__(512, 2) void conv3x3_bf16_ws_kernel(const ConvBfArgs a, int total_tiles) {
-  constexpr int TN = DM_TN, NT = TN / 32;
-  constexpr int OUT_PITCH = TN + 8;                    // bf16 per pixel row of the store-staging image
-  constexpr int SCR_OFF = DM_TF_OFF + 2 * DM_TF_MAXC * 4;   // [4 waves][2][TN] fp32 partial sums (2 KiB)
-  static_assert(512 * OUT_PITCH * 2 <= DM_BUF, "the 512-pixel staging image fits one operand buffer");
-  static_assert(SCR_OFF + 4 * 2 * TN * 4 <= 163840, "LDS budget");
-  constexpr bool bnb = (EPI & 1) != 0;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[SCR_OFF + 4 * 2 * TN * 4];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, r = lane & 31;
-  float* lds_tf = reinterpret_cast<float*>(lds + DM_TF_OFF);
-  float* scr = reinterpret_cast<float*>(lds + SCR_OFF);
-  if constexpr (TF) {
-    for (int i = tid; i < a.C0; i += 512) {
-      lds_tf[i] = a.in_scale[i];
-      lds_tf[DM_TF_MAXC + i] = a.in_shift[i];
-    }
-    __syncthreads();
-  }
-  const int Cin = a.C0 + a.C1;
-  const int Hs0 = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.mode0 ? (a.Win >> 1) : a.Win;
-  const int nchunks = Cin / 32;
-  const int G = gridDim.x;
-  auto tile_coords = [&](int tile_id, int& nt, int& sp, int& tx, int& ty, int& b) {
-    const int wg = (int)xcd_remap((unsigned)tile_id, (unsigned)total_tiles);
-    nt = wg % a.n_tiles;
-    sp = wg / a.n_tiles;
-    tx = sp % a.tiles_x;
-    ty = (sp / a.tiles_x) % a.tiles_y;
-    b = sp / (a.tiles_x * a.tiles_y);
-  };
-
-  if (wave >= 4) {
-    // ================================================================= producer waves
-    const int pw = wave - 4, ptid = tid - 256;
-    const int seg = (lane & 3) ^ ((lane >> 4) & 3);
-    constexpr int IN_PP = (DM_IN_PIECES + 3) / 4, W_PP = DM_W_PIECES / 4;   // 10 / 9 pieces per producer wave
-    int pix0[IN_PP], pix1[IN_PP], woff[W_PP];
-    auto stage_setup = [&](int tile_id) {
-      int nt, sp, tx, ty, b;
-      tile_coords(tile_id, nt, sp, tx, ty, b);
-      const int iy0 = ty * DM_TH - a.pad, ix0 = tx * DM_TW - a.pad, n0 = nt * TN;
-#pragma unroll
-      for (int i = 0; i < IN_PP; ++i) {
-        const int row = (pw + 4 * i) * 16 + (lane >> 2);
-        const int hy = row / DM_HW, hx = row - hy * DM_HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        const bool inb = row < DM_IN_ROWS && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-        bool ok0 = inb;
-        if (a.mode0 == 2) ok0 = ok0 && (((iy | ix) & 1) == 0);
-        const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
-        pix0[i] = ok0 ? (b * Hs0 + sy) * Ws0 + sx : -1;
-        pix1[i] = inb ? (b * a.Hin + iy) * a.Win + ix : -1;
-      }
-#pragma unroll
-      for (int i = 0; i < W_PP; ++i) {
-        const int row = (pw + 4 * i) * 16 + (lane >> 2);                   // weight row = tap * 64 + n
-        woff[i] = ((row >> 6) * (Cin >> 5) * a.Cout + n0 + (row & 63)) * 32 + 8 * seg;   // chunked image
-      }
-    };
-    const __bf16* zsrc = reinterpret_cast<const __bf16*>(dm_zero_block);
-    // stage chunk `chunk` of the set-up tile into buffer `buf` and wait until it is in LDS
-    auto stage = [&](int chunk, int buf) {
-      const int c0 = 32 * chunk;
-#pragma unroll
-      for (int i = 0; i < W_PP; ++i)
-        dm_dma16(a.w + (size_t)woff[i] + (size_t)chunk * a.Cout * 32, lds + buf + (DM_IN_PIECES + pw + 4 * i) * 1024);
-      const bool use0 = c0 < a.C0;
-      const __bf16* src = use0 ? a.src0 : a.src1;
-      const int C = use0 ? a.C0 : a.C1;
-      const int cc = (use0 ? c0 : c0 - a.C0) + 8 * seg;
-      if constexpr (TF) {
-        f32x4 rin[IN_PP];
-#pragma unroll
-        for (int i = 0; i < IN_PP; ++i) {
-          const int p = use0 ? pix0[i] : pix1[i];
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (pw + 4 * i < DM_IN_PIECES && p >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)p * C + cc);
-          rin[i] = v;
-        }
-        const bool tf_on = use0;      // the transform belongs to source 0
-        float sc[8], sh[8];
-        if (tf_on) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            sc[k] = lds_tf[cc + k];
-            sh[k] = lds_tf[DM_TF_MAXC + cc + k];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < IN_PP; ++i) {
-          const int ip = pw + 4 * i;
-          if (ip < DM_IN_PIECES) {
-            f32x4 raw = rin[i];
-            if (tf_on && pix0[i] >= 0) {     // padding stays zero
-              bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
-#pragma unroll
-              for (int k = 0; k < 8; ++k) {
-                float f = (float)v[k] * sc[k] + sh[k];
-                f = f < 0.f ? 0.f : f;
-                v[k] = (__bf16)f;
-              }
-              raw = *reinterpret_cast<f32x4*>(&v);
-            }
-            *reinterpret_cast<f32x4*>(lds + buf + ip * 1024 + lane * 16) = raw;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < IN_PP; ++i) {
-          const int ip = pw + 4 * i;
-          if (ip < DM_IN_PIECES) {
-            const int p = use0 ? pix0[i] : pix1[i];
-            dm_dma16(p >= 0 ? src + (size_t)p * C + cc : zsrc, lds + buf + ip * 1024);
-          }
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    };
-    // move the staged 512 x 64 bf16 image of tile `tile_id` (buffer `buf`) to HBM; finish the per-channel sums
-    constexpr int SEGS = TN / 8, PER_IT = 256 / SEGS, ITS = 512 / PER_IT;
-    const int sg = ptid % SEGS, prow = ptid / SEGS;
-    auto flush = [&](int tile_id, int buf) {
-      int nt, sp, tx, ty, b;
-      tile_coords(tile_id, nt, sp, tx, ty, b);
-      const int oy0 = ty * DM_TH, ox0 = tx * DM_TW, n0 = nt * TN;
-      const bool second = a.cout_split > 0 && n0 >= a.cout_split;
-      const int ld_all = a.cout_split > 0 ? (second ? a.Cout - a.cout_split : a.cout_split) : a.Cout;
-      __bf16* outp = second ? a.out1 : a.out;
-      const int nn0 = second ? n0 - a.cout_split : n0;
-      const __bf16* st16 = reinterpret_cast<const __bf16*>(lds + buf);
-      float q1[8], q2[8], b_mu[8], b_is[8], b_sc[8], b_sh[8];
-      if constexpr (bnb) {
-        auto ld8 = [&](const float* p, float (&v)[8]) {
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg), hi = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg + 4);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k] = lo[k];
-            v[4 + k] = hi[k];
-          }
-        };
-        ld8(a.bnb.mean, b_mu);
-        ld8(a.bnb.invstd, b_is);
-        ld8(a.bnb.act_scale, b_sc);
-        ld8(a.bnb.act_shift, b_sh);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) q1[k] = q2[k] = 0.f;
-      }
-#pragma unroll 4
-      for (int it = 0; it < ITS; ++it) {
-        const int pl = prow + it * PER_IT;
-        const int oy = oy0 + pl / DM_TW, ox = ox0 + pl % DM_TW;
-        if (oy < a.Ho && ox < a.Wo) {
-          const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld_all + nn0 + 8 * sg;
-          const f32x4 raw = *reinterpret_cast<const f32x4*>(st16 + pl * OUT_PITCH + 8 * sg);
-          *reinterpret_cast<f32x4*>(outp + o) = raw;
-          if constexpr (bnb) {   // virtual activation — the arithmetic of bn_bwd_reduce_bf16_kernel
-            const f32x4 yraw = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + o);
-            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(&raw), yv = *reinterpret_cast<const bf16x8*>(&yraw);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float yk = (float)yv[k];
-              const float act = (float)(__bf16)(yk * b_sc[k] + b_sh[k]);
-              const float g = act > 0.f ? (float)gv[k] : 0.f;
-              q1[k] += g;
-              q2[k] += g * ((yk - b_mu[k]) * b_is[k]);
-            }
-          }
-        }
-      }
-      if constexpr (bnb) {
-        // lanes with equal (lane & 7) hold the same 8 channels: butterfly over lane bits 3..5, then the 4 waves via LDS
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-          for (int o = 8; o < 64; o <<= 1) {
-            q1[k] += __shfl_xor(q1[k], o, 64);
-            q2[k] += __shfl_xor(q2[k], o, 64);
-          }
-        }
-        if (lane < 8) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            scr[(pw * 2 + 0) * TN + 8 * lane + k] = q1[k];
-            scr[(pw * 2 + 1) * TN + 8 * lane + k] = q2[k];
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-    };
-    // per-channel totals: 4 partial rows in `scr` (compute waves' statistics or the producers' own sums) -> global
-    auto write_stats = [&](int tile_id) {
-      if (a.stats == nullptr) return;
-      if (ptid < 2 * TN) {
-        int nt, sp, tx, ty, b;
-        tile_coords(tile_id, nt, sp, tx, ty, b);
-        const int which = ptid / TN, c = ptid % TN;
-        const float* rr = scr + which * TN + c;
-        a.stats[((size_t)which * a.P + sp) * a.Cout + nt * TN + c] =
-            (rr[0] + rr[2 * TN]) + (rr[4 * TN] + rr[6 * TN]);
-      }
-    };
-
-    int s_tile = blockIdx.x;
-    if (s_tile < total_tiles) {
-      stage_setup(s_tile);
-      stage(0, 0);
-    }
-    int s_chunk = 1;          // chunk of the NEXT staging step (tile s_tile)
-    if (nchunks == 1) {
-      s_chunk = 0;
-      s_tile += G;
-      if (s_tile < total_tiles) stage_setup(s_tile);
-    }
-    int step = 0, prev_tile = -1, pend_tile = -1;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
-      for (int c = 0; c < nchunks; ++c, ++step) {
-        const int nxt = ((step + 1) & 1) * DM_BUF;
-        ws_barrier();                                      // B_s: operands of this step are in place
-        if (bnb && pend_tile >= 0) {                       // every producer wave has written its partial row by now
-          write_stats(pend_tile);
-          pend_tile = -1;
-        }
-        if (c == 0 && prev_tile >= 0) {
-          ws_barrier();                                    // B': the compute waves have staged the finished tile
-          flush(prev_tile, nxt);
-          if constexpr (bnb) pend_tile = prev_tile;
-          else write_stats(prev_tile);                     // partial rows of the four compute waves
-        }
-        if (s_tile < total_tiles) {
-          stage(s_chunk, nxt);
-          if (++s_chunk == nchunks) {
-            s_chunk = 0;
-            s_tile += G;
-            if (s_tile < total_tiles) stage_setup(s_tile);
-          }
-        }
-      }
-      prev_tile = tile;
-    }
-    // the last tile: the same hand-over without a following chunk
-    if (prev_tile >= 0) {
-      const int lastbuf = ((step - 1) & 1) * DM_BUF;
-      ws_barrier();
-      if (bnb && pend_tile >= 0) write_stats(pend_tile);
-      ws_barrier();
-      flush(prev_tile, lastbuf);
-      ws_barrier();                                        // the partial rows of all producer waves are written
-      write_stats(prev_tile);
-    }
-    return;
-  }
-
-  // =================================================================== compute waves
-  const int bbase = DM_IN_PIECES * 1024 + r * 64 + ((((r >> 2) & 3) ^ h) << 4);   // + tap*4096 + j*2048, ^ (ks << 5)
-  int qb = 4 * wave * DM_HW + r;         // halo pixel of (first output row of this wave, column r)
-  f32x16 acc[4][NT];
-  auto drop_tile = [&](int tile_id, int buf) {
-    // accumulators -> bf16 staging image [512 pixels][OUT_PITCH]; BatchNorm statistics of the fp32 values -> scr
-    int nt, sp, tx, ty, b;
-    tile_coords(tile_id, nt, sp, tx, ty, b);
-    const int oy0 = ty * DM_TH, ox0 = tx * DM_TW;
-    __bf16* st16 = reinterpret_cast<__bf16*>(lds + buf);
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const bool row_ok = oy0 + 4 * wave + m < a.Ho;
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const float v = acc[m][j][i];
-          if constexpr (!bnb) {
-            if (row_ok && ox0 + mrow < a.Wo) {
-              s1[j] += v;
-              s2[j] += v * v;
-            }
-          }
-          st16[((4 * wave + m) * DM_TW + mrow) * OUT_PITCH + 32 * j + r] = (__bf16)v;
-        }
-    }
-    if constexpr (!bnb) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
-        const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-        if (h == 0) {
-          scr[(wave * 2 + 0) * TN + 32 * j + r] = t1;
-          scr[(wave * 2 + 1) * TN + 32 * j + r] = t2;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  // one chunk: 18 groups (kw, k-half, kh) of 8 MFMAs + 4 fragment reads (2 of the next B pair, 2 of the next A rows)
-  auto chunk_mma = [&](const unsigned char* bufp, auto first_tag) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    asm volatile("" : "+v"(qb));
-    bf16x8 fa[2][6], fb[3][NT];
-    auto a_addr = [&](int it, int row) {     // it = kw * 2 + ks
-      const int q = qb + row * DM_HW + (it >> 1);
-      return (q * 64 + ((((q >> 2) & 3) ^ h) << 4)) ^ ((it & 1) << 5);
-    };
-    auto load_a = [&](int it, int row, bf16x8& dst) { dst = *reinterpret_cast<const bf16x8*>(bufp + a_addr(it, row)); };
-    auto load_b = [&](int it, int kh, bf16x8 (&dst)[NT]) {
-      const int tap = kh * 3 + (it >> 1);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        dst[j] = *reinterpret_cast<const bf16x8*>(bufp + (bbase ^ ((it & 1) << 5)) + tap * 4096 + j * 2048);
-    };
-    // this wave is alone on its SIMD's matrix pipe: every fragment is requested TWO groups (>= 512 cycles) before the
-    // MFMAs that read it — the A rows of the next (kw, k-half) two per group, the B pair of group g + 2 in group g
-#pragma unroll
-    for (int row = 0; row < 6; ++row) load_a(0, row, fa[0][row]);
-    load_b(0, 0, fb[0]);
-    load_b(0, 1, fb[1]);
-#pragma unroll
-    for (int g = 0; g < 18; ++g) {
-      const int it = g / 3, kh = g % 3;
-      bf16x8 (&ac)[6] = fa[it & 1];
-      bf16x8 (&an)[6] = fa[(it & 1) ^ 1];
-      bf16x8 (&bc)[NT] = fb[g % 3];
-      asm volatile("" ::"v"(ac[kh]), "v"(ac[kh + 1]), "v"(ac[kh + 2]), "v"(ac[kh + 3]), "v"(bc[0]), "v"(bc[1]));
-      if (g + 2 < 18) load_b((g + 2) / 3, (g + 2) % 3, fb[(g + 2) % 3]);
-      if (it + 1 < 6) {
-        load_a(it + 1, 2 * kh, an[2 * kh]);
-        load_a(it + 1, 2 * kh + 1, an[2 * kh + 1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);     // reads first, then the MFMA group
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          if (FIRST && g < 1) {
-            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[m + kh], bc[j], z, 0, 0, 0);
-          } else {
-            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ac[m + kh], bc[j], acc[m][j], 0, 0, 0);
-          }
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  __builtin_amdgcn_s_setprio(1);   // the compute wave of a SIMD goes first; its producer partner fills the gaps
-  int step = 0, prev_tile = -1;
-  for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
-    for (int c = 0; c < nchunks; ++c, ++step) {
-      const int cur = (step & 1) * DM_BUF;
-      ws_barrier();                        // B_s
-      if (c == 0 && prev_tile >= 0) {
-        drop_tile(prev_tile, DM_BUF - cur);                // the buffer of the previous step: nobody reads it any more
-        ws_barrier();                      // B'
-      }
-      if (c == 0) chunk_mma(lds + cur, std::true_type{});
-      else chunk_mma(lds + cur, std::false_type{});
-    }
-    prev_tile = tile;
-  }
-  if (prev_tile >= 0) {
-    const int lastbuf = ((step - 1) & 1) * DM_BUF;
-    ws_barrier();
-    drop_tile(prev_tile, lastbuf);
-    ws_barrier();
-    ws_barrier();
-  }
-}
+// Tried and removed (round 2): a wave-specialised form of this kernel — waves 0-3 only multiply (4x2 accumulator tiles,
+// input rows reused across the 3 kernel rows: 0.5 LDS fragment reads per MFMA), waves 4-7 only move data and run the
+// previous tile's epilogue beside the next tile's MFMAs.  MEASURED (same box, B=64, scripts/bench_conv.py): 64->64
+// @128^2 404 vs 667 TFLOP/s for the symmetric kernel above, 128->128 @64^2 608 vs 796, 256->256 @32^2 817 vs 915,
+// 768->256 @32^2 1118 vs 1113: with few chunks per tile the producers' chain drop -> flush -> store drain -> stage at a
+// tile boundary (~6 us) is longer than the MFMA step it should hide behind (2.4 us), and in steady state the step time is
+// the same 4.3 us — the DMA's LDS writes and the fragment reads contend for the LDS whoever issues them.  At B=64/512^2 a
+// training step on it was also not run-to-run bit-identical (tests/test_fullsize_gpu.py), so it is not kept as an option.
 
 // DT_BF16_DMA in the environment: 0 keeps every layer on the register-staged kernels (A/B measurements), 2 uses this
 // kernel wherever its shape conditions hold (tests on small batches); default 1: only where its tiles fill the chip
 static int g_dm_mode = -1;
-static int g_dm_ws = 0;      // wave-specialised form for the plain-store epilogues: option "bf16_ws" / DT_BF16_WS=1.
-                             // OFF by default: measured slower (see the note above conv3x3_bf16_ws_kernel)
 static int dm_mode() {
   if (g_dm_mode < 0) {
     const char* e = getenv("DT_BF16_DMA");
     g_dm_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
-    const char* w = getenv("DT_BF16_WS");
-    if (w && (w[0] == '0' || w[0] == '1')) g_dm_ws = w[0] - '0';
   }
   return g_dm_mode;
 }
@@ -889,10 +494,6 @@ extern "C" int dt_set_option(const char* name, int value) {
   if (strcmp(name, "bf16_dma") == 0) {
     DT_REQUIRE(value >= 0 && value <= 2, "set_option: bf16_dma takes 0 (off), 1 (auto) or 2 (wherever the shape allows)");
     g_dm_mode = value;
-    return DT_OK;
-  }
-  if (strcmp(name, "bf16_ws") == 0) {
-    g_dm_ws = value != 0;
     return DT_OK;
   }
   dt_set_error("set_option: unknown option '%s'", name);
@@ -926,16 +527,10 @@ int dt_conv_bf16_dma_launch(ConvBfArgs a, hipStream_t st) {
   const int grid = total < DM_MAX_WGS ? total : DM_MAX_WGS;
   const bool bnb = a.bnb.y != nullptr, join = a.accumulate != 0;
   DT_REQUIRE(!bnb || a.stats != nullptr, "conv_bf16_dma: fused BatchNorm-backward sums need the stats buffer");
-  DT_REQUIRE(!(a.in_scale != nullptr && (bnb || join)), "conv_bf16_dma: input transform goes with forward convolutions only");
+  DT_REQUIRE(!(a.in_scale != nullptr && bnb), "conv_bf16_dma: no input transform on the BatchNorm-backward form");
   dim3 g((unsigned)grid), blk(512);
-  if (!join && g_dm_ws) {     // plain-store epilogues: the wave-specialised kernel
-    if (a.in_scale != nullptr) hipLaunchKernelGGL((conv3x3_bf16_ws_kernel<true, 0>), g, blk, 0, st, a, total);
-    else if (!bnb) hipLaunchKernelGGL((conv3x3_bf16_ws_kernel<false, 0>), g, blk, 0, st, a, total);
-    else hipLaunchKernelGGL((conv3x3_bf16_ws_kernel<false, 1>), g, blk, 0, st, a, total);
-    DT_LAUNCH_CHECK();
-    return DT_OK;
-  }
-  if (a.in_scale != nullptr) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<true, 0>), g, blk, 0, st, a, total);
+  if (a.in_scale != nullptr && join) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<true, 2>), g, blk, 0, st, a, total);
+  else if (a.in_scale != nullptr) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<true, 0>), g, blk, 0, st, a, total);
   else if (!bnb && !join) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false, 0>), g, blk, 0, st, a, total);
   else if (bnb && !join) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false, 1>), g, blk, 0, st, a, total);
   else if (!bnb && join) hipLaunchKernelGGL((conv3x3_bf16_dma_kernel<false, 2>), g, blk, 0, st, a, total);

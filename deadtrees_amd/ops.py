@@ -66,6 +66,44 @@ def conv2d(src0, w_hwio, k, stride, pad, src1=None, mode0=0, split=0, out0=None,
     return out0, out1, stats
 
 
+def winograd_weights(w_hwio):
+    """U = G g G^T of a 3x3 HWIO weight in the Winograd kernel's image order [16][Cin/8][2][Cout][4]."""
+    _gpu(w_hwio)
+    k, _, cin, cout = w_hwio.shape
+    assert k == 3
+    u = torch.empty((16, cin // 8, 2, cout, 4), dtype=torch.float32, device=w_hwio.device)
+    _lib.check(_lib.load().dt_winograd_weights(_p(w_hwio.contiguous()), _p(u), cin, cout, _st()), "dt_winograd_weights")
+    return u
+
+
+def conv2d_winograd(src0, u, src1=None, mode0=0, split=0, out0=None, out1=None, accumulate=False, want_stats=False,
+                    in_scale=None, in_shift=None):
+    """3x3 stride-1 pad-1 NHWC conv through dt_conv2d_winograd.  Returns (out0, out1, stats[2,P,Cout] or None)."""
+    _gpu(src0, src1, u)
+    lib = _lib.load()
+    B, C0 = src0.shape[0], src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    Hin, Win = (src0.shape[1], src0.shape[2]) if mode0 == 0 else (2 * src0.shape[1], 2 * src0.shape[2])
+    Cout = u.shape[3]
+    d = conv_desc(B, Hin, Win, C0, C1, mode0, Cout, 3, 1, 1, split, 1 if accumulate else 0)
+    if not lib.dt_conv2d_winograd_supported(C.byref(d)):
+        raise ValueError("layer shape not supported by the Winograd kernel")
+    dev = src0.device
+    if out0 is None:
+        out0 = torch.empty((B, d.Ho, d.Wo, split if split else Cout), dtype=torch.float32, device=dev)
+    if split and out1 is None:
+        out1 = torch.empty((B, d.Ho, d.Wo, Cout - split), dtype=torch.float32, device=dev)
+    stats = None
+    if want_stats:
+        P = lib.dt_conv2d_winograd_stat_rows(C.byref(d))
+        stats = torch.empty(lib.dt_bn_stats_floats(P, Cout), dtype=torch.float32, device=dev)
+    _lib.check(lib.dt_conv2d_winograd(C.byref(d), _p(src0), _p(src1), _p(u), _p(out0), _p(out1), _p(stats),
+                                      _p(in_scale), _p(in_shift), _st()), "dt_conv2d_winograd")
+    if stats is not None:
+        stats = stats[:2 * P * Cout].view(2, P, Cout)
+    return out0, out1, stats
+
+
 def weight_flip_transpose(w_hwio):
     _gpu(w_hwio)
     k, _, cin, cout = w_hwio.shape

@@ -75,6 +75,17 @@ int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const
 int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck);
 int dt_conv2d_uses_zi(const dt_conv_desc* d);  /* 1: parity-class tiles of the transposed (stride-2) data gradient */
 
+/* ---- Winograd F(2x2,3x3) form of the 3x3 stride-1 pad-1 layers (same ATen conv2d / convolution_backward(input)
+ * calls as dt_conv2d; 2.25x fewer multiplies, results within ~1e-6 relative of the direct form instead of an exact fma
+ * chain).  u = dt_winograd_weights(w_hwio): G g G^T in the order [16 positions][Cin/8][2][Cout][4], 16*Cin*Cout floats.
+ * Supported when C0, C1 are multiples of 8, Cout and cout_split multiples of 64, mode0 in {0,1}, sources < 2 GiB.
+ * stats rows: dt_conv2d_winograd_stat_rows (16x16-pixel tiles). */
+int dt_conv2d_winograd_supported(const dt_conv_desc* d);
+int dt_conv2d_winograd_stat_rows(const dt_conv_desc* d);
+int dt_winograd_weights(const float* w_hwio, float* u, int Cin, int Cout, void* stream);
+int dt_conv2d_winograd(const dt_conv_desc* d, const float* src0, const float* src1, const float* u, float* out0,
+                       float* out1, float* stats, const float* in_scale, const float* in_shift, void* stream);
+
 /* wd[kh'][kw'][co][ci] = w[K-1-kh'][K-1-kw'][ci][co]: weights of the data-gradient convolution. */
 int dt_weight_flip_transpose(const float* w_hwio, float* wd, int ksize, int Cin, int Cout, void* stream);
 
@@ -382,9 +393,7 @@ int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, co
 /* Kernel-selection switches (host side, process wide; every choice computes the same values):
  *   "bf16_dma": 0 = register-staged bf16 convolutions only, 1 (default) = the LDS-DMA staged 512-pixel kernel where
  *               its tiles fill the chip, 2 = wherever its shape conditions hold.  Also read from the environment
- *               variable DT_BF16_DMA at first use.
- *   "bf16_ws":  1 = plain-store launches of that kernel use its wave-specialised form (4 compute + 4 producer waves;
- *               measured slower, kept for experiments), 0 (default) = all eight waves do both.  Env: DT_BF16_WS. */
+ *               variable DT_BF16_DMA at first use. */
 int dt_set_option(const char* name, int value);
 
 #ifdef __cplusplus

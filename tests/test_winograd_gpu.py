@@ -1,0 +1,81 @@
+"""Winograd F(2x2,3x3) fp32 convolution (conv_wino.hip) against torch CPU fp64 and against the direct kernel.
+
+Tolerance: the transforms add/subtract inputs before multiplying (|B^T d B| <= 4 max|d|, products of (G g G^T) with
+coefficients 1/4..1) and the output transform sums 9 of the 16 products, so the result is no longer an exact fp32 fma
+chain: error ~ a few 1e-6 of max|y| per sqrt(K/1000) — bounded here at 1e-5 * max|y| (the direct kernel: 2e-6)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from deadtrees_amd import ops
+    return ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2).double()
+
+
+CASES = [  # B, H, W (stored size of source 0), C0, C1, mode0, Cout, split, transform
+    (2, 32, 32, 64, 0, 0, 64, 0, False), (1, 34, 70, 512, 0, 0, 64, 0, True), (3, 17, 33, 32, 0, 0, 128, 0, False),
+    (2, 16, 20, 64, 32, 1, 128, 0, True), (2, 16, 24, 128, 64, 1, 64, 0, False), (2, 40, 48, 64, 0, 0, 192, 64, False),
+    (2, 16, 16, 8, 0, 0, 64, 0, False), (1, 5, 7, 16, 8, 0, 64, 0, True)]
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,split,tf", CASES)
+def test_winograd_conv_matches_fp64_and_direct_kernel(B, H, W, C0, C1, mode0, Cout, split, tf):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + H + C0 + Cout)
+    x = torch.randn((B, C0, H, W), generator=g)
+    Hin, Win = (H, W) if mode0 == 0 else (2 * H, 2 * W)
+    s1 = torch.randn((B, C1, Hin, Win), generator=g) if C1 else None
+    wt = torch.randn((Cout, C0 + C1, 3, 3), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5
+    sc = 1 + 0.3 * torch.randn(C0, generator=g) if tf else None
+    sh = 0.3 * torch.randn(C0, generator=g) + 0.2 if tf else None
+    z = x.double()
+    if tf:
+        z = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]).double()   # fp32 affine like the kernel
+    if mode0 == 1:
+        z = F.interpolate(z, scale_factor=2, mode="nearest")
+    xin = torch.cat([z, s1.double()], 1) if C1 else z
+    ref = F.conv2d(xin, wt.double(), padding=1)
+    w_hwio = wt.permute(2, 3, 1, 0).contiguous().to(DEV)
+    u = ops.winograd_weights(w_hwio)
+    kw = dict(src1=nhwc(s1) if C1 else None, mode0=mode0, in_scale=sc.to(DEV) if tf else None,
+              in_shift=sh.to(DEV) if tf else None)
+    scale = float(ref.abs().max())
+    if split:
+        base = torch.randn((B, Hin, Win, split), generator=g).to(DEV)
+        o0, o1, _ = ops.conv2d_winograd(nhwc(x), u, split=split, out0=base.clone(), accumulate=True, **kw)
+        got = torch.cat([nchw(o0) - nchw(base), nchw(o1)], 1)
+        assert float((got - ref).abs().max()) <= 1e-5 * scale + 1e-6 * float(base.abs().max())
+        return
+    y, _, st = ops.conv2d_winograd(nhwc(x), u, want_stats=True, **kw)
+    got = nchw(y)
+    assert float((got - ref).abs().max()) <= 1e-5 * scale
+    np.testing.assert_allclose(st[0].double().sum(0).cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-4,
+                               atol=1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max()))
+    np.testing.assert_allclose(st[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4)
+    d, _, _ = ops.conv2d(nhwc(x), w_hwio, 3, 1, 1, **kw)
+    assert float((nchw(d) - got).abs().max()) <= 1e-5 * scale
+
+
+def test_winograd_weight_transform():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    Cin, Cout = 24, 64
+    w = torch.randn((3, 3, Cin, Cout), generator=g, dtype=torch.float64)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    want = torch.einsum("ia,abco,jb->ijco", G, w, G)             # [4][4][Cin][Cout]
+    u = ops.winograd_weights(w.float().to(DEV)).cpu().double()   # [16][Cin/8][2][Cout][4]
+    got = u.permute(0, 1, 2, 4, 3).reshape(16, Cin, Cout).reshape(4, 4, Cin, Cout)
+    assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
