@@ -34,6 +34,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define WN_PS 288                      // floats per (position, k-half) plane: 64 x 4 + 32 (bank skew for the V writes)
 #define WN_BUF (32 * WN_PS)            // one operand image of one chunk: 36,864 B
 #define WN_TF_MAXC 512
+#define WN_MAX_WGS 256                 // CUs of an MI355X
 #define WN_OOB 0x80000000u             // byte offset beyond every buffer this kernel takes (host check: < 2 GiB)
 
 struct WinoArgs {
@@ -50,6 +51,8 @@ struct WinoArgs {
   int Cout, cout_split, accumulate;
   int tiles_x, tiles_y, n_tiles, P, nchunks;
   unsigned bytes0, bytes1;   // sizes of the two sources (buffer descriptors: out-of-range loads return 0)
+  unsigned obytes0, obytes1; // sizes of the two outputs
+  unsigned ubytes;           // size of the transformed weights
 };
 
 // compile-time loop: the slot schedule below indexes register arrays (accumulators, patch pixels) with k — an ordinary
@@ -68,12 +71,21 @@ __device__ __forceinline__ void wn_dma16(const void* g, void* l) {
 
 // EPI: 0 store (+ BatchNorm statistics, split outputs); 1 store + fused BatchNorm-backward sums (virtual activation);
 //      2 gradient join (out0 += ...); 3 join + BatchNorm-backward sums (stored activation)
+//
+// Persistent workgroups (one per CU): workgroup g walks the tiles xcd_remap(g + round * grid) — the n-tiles of one
+// spatial tile run at the same time on one XCD and share its L2 — as ONE sequence of steps (tile, 8-channel chunk).
+// During step s (64 MFMAs of 64 cycles per wave; everything else is issued in their shadow, a few instructions after
+// each one) the wave also issues: the weight-plane DMAs of step s+1, the 16 patch-pixel loads of step s+2 (two register
+// sets: a full step of latency cover, across tile boundaries too), and the BatchNorm+ReLU / B^T d B transform / LDS
+// writes of step s+1.  One barrier per step; at a tile's last step the epilogue runs with the next tile's operands
+// already in flight.
 template <bool TF, int EPI>
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) {
-  __shared__ __attribute__((aligned(1024))) float lds[4 * WN_BUF + (TF ? 2 * WN_TF_MAXC : 4)];
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, const int total_tiles) {
+  __shared__ __attribute__((aligned(1024))) float lds[4 * WN_BUF + 256 + (TF ? 2 * WN_TF_MAXC : 0)];
   float* Vb = lds;
   float* Ub = lds + 2 * WN_BUF;
-  float* lds_tf = lds + 4 * WN_BUF;
+  float* red = lds + 4 * WN_BUF;     // [2][2 m-waves][64] BatchNorm partial sums of a tile
+  float* lds_tf = red + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if constexpr (TF) {
     for (int i = tid; i < a.C0; i += 256) {
@@ -82,64 +94,111 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     }
   }
   const int wm = wave >> 1, wn = wave & 1, kh = lane >> 5, r = lane & 31;
+  const int q = tid & 3, wt = tid >> 2;     // staging role: Winograd tile wt (8 x 8 per workgroup), channel pair q
+  const int nch = a.nchunks;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  auto tile_of_round = [&](int round) { return (int)xcd_remap(blockIdx.x + (unsigned)round * gridDim.x, (unsigned)total_tiles); };
 
-  const int wg = (int)xcd_remap(blockIdx.x, gridDim.x);   // n-tiles of one spatial tile share an XCD's L2
-  const int nt = wg % a.n_tiles;
-  const int sp = wg / a.n_tiles;
-  const int tx = sp % a.tiles_x;
-  const int ty = (sp / a.tiles_x) % a.tiles_y;
-  const int b = sp / (a.tiles_x * a.tiles_y);
-  const int oy0 = ty * 16, ox0 = tx * 16, n0 = nt * 64;
-
-  // ---- staging role: Winograd tile wt (8 x 8 per workgroup), channel pair q of the chunk.  Byte offsets of the 16
-  // patch pixels in source 0 / source 1; WN_OOB (beyond num_records of the buffer descriptor -> the load returns 0)
-  // for padding.  One buffer_load_dwordx2 per pixel and chunk, no branches, no 64-bit address arithmetic.
-  const int q = tid & 3, wt = tid >> 2;
+  // ---- load context (runs two steps ahead): byte offsets of the 16 patch pixels in source 0 / source 1; WN_OOB
+  // (beyond num_records of the buffer descriptor -> the load returns 0) for padding and past the last tile.
+  // One buffer_load_dwordx2 per pixel and chunk: no branches, no 64-bit address arithmetic.
   unsigned off0[16], off1[16];
-  {
-    const int iy = oy0 - 1 + 2 * (wt >> 3), ix = ox0 - 1 + 2 * (wt & 7);
+  int l_round = 0, l_chunk = 0;
+  auto setup_offsets = [&](int round) {
+    const bool live = round < my_tiles;
+    const int tile = live ? tile_of_round(round) : 0;
+    const int sp = tile / a.n_tiles;
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / tiles_per_img;
+    const int iy = 16 * ty - 1 + 2 * (wt >> 3), ix = 16 * tx - 1 + 2 * (wt & 7);
     const int Hs0 = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.mode0 ? (a.Win >> 1) : a.Win;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int y = iy + i, x = ix + j;
-        const bool ok = (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        const bool ok = live && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         const int p0 = (b * Hs0 + (a.mode0 ? (y >> 1) : y)) * Ws0 + (a.mode0 ? (x >> 1) : x);
         const int p1 = (b * a.Hin + y) * a.Win + x;
         off0[4 * i + j] = ok ? (unsigned)(p0 * a.C0 + 2 * q) * 4u : WN_OOB;
         off1[4 * i + j] = ok ? (unsigned)(p1 * a.C1 + 2 * q) * 4u : WN_OOB;
       }
-  }
+  };
+  auto advance_loads = [&]() {
+    if (++l_chunk == nch) {
+      l_chunk = 0;
+      setup_offsets(++l_round);
+    }
+  };
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, a.bytes0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src1 ? a.src1 : a.src0), 0, a.bytes1, 0x00020000);
-  f32x2 d[16], t[16];
-  auto load_pixel = [&](int i, int c0) {
+  f32x2 d[2][16], t[16];
+  int dc0[2] = {0, 0};               // first channel of the chunk each register set holds
+  auto load_pixel = [&](auto set_tag, int i) {
+    constexpr int SET = decltype(set_tag)::value;
+    const int c0 = __builtin_amdgcn_readfirstlane(8 * l_chunk);
     const bool use0 = c0 < a.C0;   // wave-uniform
     const unsigned cb = (unsigned)(use0 ? c0 : c0 - a.C0) * 4u;
     const u32x2 v = use0 ? __builtin_amdgcn_raw_buffer_load_b64(rs0, off0[i] + cb, 0, 0)
                          : __builtin_amdgcn_raw_buffer_load_b64(rs1, off1[i] + cb, 0, 0);
-    d[i] = __builtin_bit_cast(f32x2, v);
+    d[SET][i] = __builtin_bit_cast(f32x2, v);
+    if (i == 0) dc0[SET] = c0;
   };
-  // the producer's BatchNorm-apply + ReLU on the real pixels of source 0 (zero padding stays zero)
-  auto tf_pixel = [&](int i, int c0) {
+  // the producer's BatchNorm-apply + ReLU on the real pixels of source 0 (zero padding stays zero: a padded pixel was
+  // loaded as exactly 0 and is recognised by the validity bit taken when the set was loaded)
+  unsigned dval[2] = {0, 0};
+  f32x2 tf_sc = {1.f, 1.f}, tf_sh = {0.f, 0.f}, tf_v[2];
+  float tf_lo = 0.f;
+  // branch-free: a chunk of source 1 (no transform) runs with scale 1, shift 0 and a ReLU floor of -inf
+  auto tf_begin = [&](auto set_tag) {
     if constexpr (TF) {
-      if (c0 < a.C0) {
-        const f32x2 sc = *reinterpret_cast<const f32x2*>(lds_tf + c0 + 2 * q);
-        const f32x2 sh = *reinterpret_cast<const f32x2*>(lds_tf + WN_TF_MAXC + c0 + 2 * q);
-        f32x2 v = d[i] * sc + sh;
-        v[0] = v[0] < 0.f ? 0.f : v[0];
-        v[1] = v[1] < 0.f ? 0.f : v[1];
-        d[i] = off0[i] != WN_OOB ? v : d[i];
-      }
+      constexpr int SET = decltype(set_tag)::value;
+      const int c0 = __builtin_amdgcn_readfirstlane(dc0[SET]);
+      const bool on = c0 < a.C0;
+      const int tc = on ? c0 : 0;
+      const f32x2 sc = *reinterpret_cast<const f32x2*>(lds_tf + tc + 2 * q);
+      const f32x2 sh = *reinterpret_cast<const f32x2*>(lds_tf + WN_TF_MAXC + tc + 2 * q);
+      tf_sc[0] = on ? sc[0] : 1.f;
+      tf_sc[1] = on ? sc[1] : 1.f;
+      tf_sh[0] = on ? sh[0] : 0.f;
+      tf_sh[1] = on ? sh[1] : 0.f;
+      tf_lo = on ? 0.f : -__builtin_inff();
+    }
+  };
+  // two half-steps per pixel, issued one MFMA apart (a single wave per SIMD: dependent VALU chains need the distance)
+  auto tf_a = [&](auto set_tag, int i) {
+    if constexpr (TF) {
+      constexpr int SET = decltype(set_tag)::value;
+      tf_v[i & 1] = d[SET][i] * tf_sc + tf_sh;
+    }
+  };
+  auto tf_b = [&](auto set_tag, int i) {
+    if constexpr (TF) {
+      constexpr int SET = decltype(set_tag)::value;
+      f32x2 v = tf_v[i & 1];
+      v[0] = __builtin_fmaxf(v[0], tf_lo);
+      v[1] = __builtin_fmaxf(v[1], tf_lo);
+      const bool valid = ((dval[SET] >> i) & 1u) != 0;   // a padded pixel was loaded as exactly 0 and stays 0
+      d[SET][i][0] = valid ? v[0] : d[SET][i][0];
+      d[SET][i][1] = valid ? v[1] : d[SET][i][1];
+    }
+  };
+  auto mark_valid = [&](auto set_tag) {
+    if constexpr (TF) {
+      constexpr int SET = decltype(set_tag)::value;
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m |= (off0[i] != WN_OOB ? 1u : 0u) << i;
+      dval[SET] = m;
     }
   };
   // B^T d B in registers: column j of B^T d, then row i of (B^T d) B -> 4 positions of (tile wt, channels 2q, 2q+1)
-  auto transform_col = [&](int j) {
-    t[0 + j] = d[0 + j] - d[8 + j];
-    t[4 + j] = d[4 + j] + d[8 + j];
-    t[8 + j] = d[8 + j] - d[4 + j];
-    t[12 + j] = d[4 + j] - d[12 + j];
+  auto transform_col = [&](auto set_tag, int j) {
+    constexpr int SET = decltype(set_tag)::value;
+    t[0 + j] = d[SET][0 + j] - d[SET][8 + j];
+    t[4 + j] = d[SET][4 + j] + d[SET][8 + j];
+    t[8 + j] = d[SET][8 + j] - d[SET][4 + j];
+    t[12 + j] = d[SET][4 + j] - d[SET][12 + j];
   };
   const int vwoff = (q >> 1) * WN_PS + wt * 4 + 2 * (q & 1);
   auto transform_row_write = [&](float* Vd, int i) {
@@ -153,12 +212,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
     *reinterpret_cast<f32x2*>(dst + (4 * i + 2) * 2 * WN_PS) = v2;
     *reinterpret_cast<f32x2*>(dst + (4 * i + 3) * 2 * WN_PS) = v3;
   };
-  // transformed weights of chunk `ch`: 32 planes of 1 KiB, 8 per wave, straight into LDS
-  const float* ug = a.u + (size_t)(n0 + lane) * 4;
-  auto dma_plane = [&](float* Ud, int ch, int i) {
-    const int plane = wave * 8 + i;
+  // ---- weight context (one step ahead): transformed weights of (tile, chunk): 32 planes of 1 KiB, 8 per wave, by DMA
+  // (buffer_load_dwordx4 ... lds: per-lane part (n0 + lane) * 16 B in the VGPR offset, everything else scalar)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wave_m = wave_u >> 1;
+  const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, a.ubytes, 0x00020000);
+  int w_round = 0, w_chunk = 0;
+  unsigned u_voff = 0;
+  auto set_ug = [&](int round) {
+    const int tile = tile_of_round(round < my_tiles ? round : 0);   // past the end: any valid address (never multiplied)
+    u_voff = (unsigned)((tile % a.n_tiles) * 64 + lane) * 16u;
+  };
+  auto dma_plane = [&](float* Ud, int i) {
+    const int plane = wave_u * 8 + i;
     const int pos = plane >> 1, k = plane & 1;
-    wn_dma16(ug + (((size_t)pos * a.nchunks + ch) * 2 + k) * (size_t)a.Cout * 4, Ud + plane * WN_PS);
+    const int ch = __builtin_amdgcn_readfirstlane(w_chunk);
+    const int soff = ((pos * nch + ch) * 2 + k) * a.Cout * 16;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsu, (wn_lptr)(Ud + plane * WN_PS), 16, u_voff, soff, 0, 0);
+  };
+  auto advance_weights = [&]() {
+    if (++w_chunk == nch) {
+      w_chunk = 0;
+      set_ug(++w_round);
+    }
   };
 
   f32x16 acc[16];
@@ -169,33 +245,45 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
 
   const int aoff = kh * WN_PS + (32 * wm + r) * 4;
   const int boff = kh * WN_PS + (32 * wn + r) * 4;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
   if constexpr (TF) __syncthreads();   // lds_tf
-  // ---- prologue: chunk 0 (exposed once per tile)
+  // ---- prologue: step 0 staged completely, the loads of step 1 in flight
+  setup_offsets(0);
+  set_ug(0);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) load_pixel(i, 0);
+  for (int i = 0; i < 8; ++i) dma_plane(Ub, i);
+  advance_weights();
+  mark_valid(S0{});
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dma_plane(Ub, 0, i);
+  for (int i = 0; i < 16; ++i) load_pixel(S0{}, i);
+  advance_loads();
+  mark_valid(S1{});
 #pragma unroll
-  for (int i = 0; i < 16; ++i) tf_pixel(i, 0);
+  for (int i = 0; i < 16; ++i) load_pixel(S1{}, i);
+  advance_loads();
+  tf_begin(S0{});
 #pragma unroll
-  for (int j = 0; j < 4; ++j) transform_col(j);
+  for (int i = 0; i < 16; ++i) {
+    tf_a(S0{}, i);
+    tf_b(S0{}, i);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) transform_col(S0{}, j);
 #pragma unroll
   for (int i = 0; i < 4; ++i) transform_row_write(Vb, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the weight planes of step 0
 
-  // ---- one chunk: 16 positions x 4 k-steps = 64 MFMAs of 64 cycles; everything else is issued in their shadow, a few
-  // instructions after each one (slot k = 4 p + j): the next position's fragments right after the first MFMA of a
-  // position; chunk c+1's 16 pixel loads and 8 weight-plane DMAs in slots 1..23; BatchNorm+ReLU of the loaded pixels in
-  // 32..39 and the input transform + its 16 LDS writes in 40..47.
-  auto chunk = [&](int c, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight planes of chunk c have landed
-    __syncthreads();                                   // everybody's V / U of chunk c; nobody reads the other images
-    const float* Vc = Vb + (c & 1) * WN_BUF + aoff;
-    const float* Uc = Ub + (c & 1) * WN_BUF + boff;
-    float* Vn = Vb + ((c + 1) & 1) * WN_BUF;
-    float* Un = Ub + ((c + 1) & 1) * WN_BUF;
-    const int c1 = 8 * (c + 1);
+  // ---- one step.  PAR = s & 1: operand images PAR are multiplied; images PAR^1 receive step s+1; register set PAR^1
+  // (loaded during step s-1) is transformed; register set PAR is loaded for step s+2.
+  auto step = [&](auto par_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    using SN = std::integral_constant<int, PAR ^ 1>;
+    const float* Vc = Vb + PAR * WN_BUF + aoff;
+    const float* Uc = Ub + PAR * WN_BUF + boff;
+    float* Vn = Vb + (PAR ^ 1) * WN_BUF;
+    float* Un = Ub + (PAR ^ 1) * WN_BUF;
     f32x4 fa[2], fb[2];
     fa[0] = *reinterpret_cast<const f32x4*>(Vc);
     fb[0] = *reinterpret_cast<const f32x4*>(Uc);
@@ -211,142 +299,181 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a) 
         fa[cur ^ 1] = *reinterpret_cast<const f32x4*>(Vc + (p + 1) * 2 * WN_PS);
         fb[cur ^ 1] = *reinterpret_cast<const f32x4*>(Uc + (p + 1) * 2 * WN_PS);
       }
-      if constexpr (MORE) {
-#if !(defined(WN_ABLATE) && WN_ABLATE == 1)   // 1: no staging after the first chunk
-        if (j != 0 && k < 24) {
-          const int li = 3 * p + (j - 1);   // 0..17
-#if !(defined(WN_ABLATE) && WN_ABLATE == 4)   // 4: weight DMA only
-          if (li < 16) load_pixel(li, c1);
-#endif
+#if !(defined(WN_ABLATE) && WN_ABLATE == 1)   // 1: no staging after the prologue
 #if !(defined(WN_ABLATE) && WN_ABLATE == 5)   // 5: input loads + transform only
-          if (li >= 8 && li < 16) dma_plane(Un, c + 1, li - 8);
-#endif
-        }
-#if !(defined(WN_ABLATE) && WN_ABLATE == 4)
-        if (k >= 32 && k < 40) {
-          tf_pixel(2 * (k - 32), c1);
-          tf_pixel(2 * (k - 32) + 1, c1);
-        }
-        if (k >= 40 && k < 44) transform_col(k - 40);
-        if (k >= 44 && k < 48) transform_row_write(Vn, k - 44);
-#endif
-#endif
+      if (j != 0 && k >= 22 && k < 34) {      // slots 22..31: the 8 weight planes of step s+1
+        constexpr int wi = 3 * p + (j - 1) - 16;   // k = 22, 23, 25, 26, 27, 29, 30, 31 -> 0..7
+        if (wi >= 0 && wi < 8) dma_plane(Un, wi);
       }
+#endif
+#if !(defined(WN_ABLATE) && WN_ABLATE == 4)   // 4: weight DMA only
+      if (j != 0 && k < 22) {                 // slots 1..21: the 16 patch pixels of step s+2 (issued first: they come
+        constexpr int li = 3 * p + (j - 1);   // from HBM, the weights from L2)
+        if (li == 0) mark_valid(par_tag);
+        if (li < 16) load_pixel(par_tag, li);
+      }
+      if (k == 34) tf_begin(SN{});
+      if (k >= 35 && k < 51) tf_a(SN{}, k - 35);
+      if (k >= 36 && k < 52) tf_b(SN{}, k - 36);
+      if (k >= 52 && k < 56) transform_col(SN{}, k - 52);
+      if (k >= 56 && k < 60) transform_row_write(Vn, k - 56);
+#endif
+      if (k == 60) {
+        advance_weights();
+        advance_loads();
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     });
+    // this wave's weight planes of step s+1 (issued >= 32 MFMAs ago) and patch pixels of step s+2 (>= 42 MFMAs ago)
+    // have landed.  A plain vmcnt(0): a counted wait would have to know how many spill accesses hipcc put in between.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  for (int c = 0; c + 1 < a.nchunks; ++c) chunk(c, std::true_type{});
-  chunk(a.nchunks - 1, std::false_type{});
 
+  // ---- epilogue of one tile: output transform A^T M A (lane-local on the accumulators), stores, BatchNorm sums
+  auto epilogue = [&](int round) {
 #if defined(WN_ABLATE) && WN_ABLATE == 2     // throw-away measurement build: no epilogue
 #pragma unroll
-  for (int p = 0; p < 16; ++p) asm volatile("" ::"v"(acc[p]));
-  return;
+    for (int p = 0; p < 16; ++p) asm volatile("" ::"v"(acc[p]));
+    return;
 #endif
-  // ---------------- output transform A^T M A (lane-local) + epilogue
-  const int n = n0 + 32 * wn + r;
-  float* outp = a.out0;
-  int ld = a.Cout, nn = n;
-  if (a.cout_split > 0) {
-    if (n0 >= a.cout_split) {
-      outp = a.out1; ld = a.Cout - a.cout_split; nn = n - a.cout_split;
-    } else {
-      ld = a.cout_split;
+    const int tile = tile_of_round(round);
+    const int nt = tile % a.n_tiles, sp = tile / a.n_tiles;
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / tiles_per_img;
+    const int oy0 = 16 * ty, ox0 = 16 * tx, n0 = 64 * nt;
+    const int n = n0 + 32 * wn + r;
+    float* outp = a.out0;
+    int ld = a.Cout, nn = n;
+    if (a.cout_split > 0) {
+      if (n0 >= a.cout_split) {
+        outp = a.out1; ld = a.Cout - a.cout_split; nn = n - a.cout_split;
+      } else {
+        ld = a.cout_split;
+      }
     }
-  }
-  float s1 = 0.f, s2 = 0.f;
-  float b_mu = 0.f, b_is = 0.f, b_sc = 0.f, b_sh = 0.f;
-  if constexpr (EPI == 1 || EPI == 3) {
-    b_mu = a.bnb.mean[n];
-    b_is = a.bnb.invstd[n];
-    if constexpr (EPI == 1) {
-      b_sc = a.bnb.act_scale[n];
-      b_sh = a.bnb.act_shift[n];
+    float s1 = 0.f, s2 = 0.f;
+    float b_mu = 0.f, b_is = 0.f, b_sc = 0.f, b_sh = 0.f;
+    if constexpr (EPI == 1 || EPI == 3) {
+      b_mu = a.bnb.mean[n];
+      b_is = a.bnb.invstd[n];
+      if constexpr (EPI == 1) {
+        b_sc = a.bnb.act_scale[n];
+        b_sh = a.bnb.act_shift[n];
+      }
     }
-  }
+    const bool second = outp == a.out1 && a.cout_split > 0;
+    const bool join = EPI >= 2 && !second;   // split data gradients accumulate into out0 only
+    // 32-bit byte offsets + buffer descriptors: a pixel outside the map gets WN_OOB -> its loads return 0 and its store
+    // is dropped by the range check (no branches); y / act of the fused BatchNorm-backward forms share out0's layout
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, second ? a.obytes1 : a.obytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bnb.y ? a.bnb.y : outp), 0, a.obytes0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bnb.act ? a.bnb.act : outp), 0, a.obytes0, 0x00020000);
+    // addressing: byte offset = [tile base + (row, column) of the output inside the wave's block: scalar, in the
+    // buffer op's SGPR offset] + [the lane's own part: 1 VGPR]; a pixel outside the map gets WN_OOB in the VGPR part
+    const int ld4 = ld * 4, row4 = a.Win * ld4;
+    const int tile_base = ((b * a.Hin + oy0 + 8 * wave_m) * a.Win + ox0) * ld4;   // rows 8 wm .. 8 wm + 7 of the tile
+    const unsigned lane_base = (unsigned)(8 * kh * ld4 + nn * 4);
+    const int xlane = ox0 + 8 * kh, ybase = oy0 + 8 * wave_m;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int m = (i & 3) + 8 * (i >> 2) + 4 * kh;
-    const int t = 32 * wm + m;
-    const int oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
-    float t0[4], t1[4];
+    for (int qr = 0; qr < 4; ++qr) {
+      // 4 accumulator rows (4 Winograd tiles x 4 pixels) at a time: the reads of this quarter are in flight while its
+      // output transforms are computed; the scheduling fence keeps hipcc from hoisting all 256 accumulator reads
+      unsigned off[16];
+      int soff[16];
+      float prev[(EPI >= 2) ? 16 : 1], yv[(EPI == 1 || EPI == 3) ? 16 : 1], zv[(EPI == 3) ? 16 : 1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      t0[j] = acc[0 + j][i] + acc[4 + j][i] + acc[8 + j][i];
-      t1[j] = acc[4 + j][i] - acc[8 + j][i] - acc[12 + j][i];
-    }
-    float y[4];
-    y[0] = t0[0] + t0[1] + t0[2];
-    y[1] = t0[1] - t0[2] - t0[3];
-    y[2] = t1[0] + t1[1] + t1[2];
-    y[3] = t1[1] - t1[2] - t1[3];
-    size_t off[4];
-    bool ok[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int py = oy + (e >> 1), px = ox + (e & 1);
-      ok[e] = py < a.Hin && px < a.Win;
-      off[e] = (((size_t)b * a.Hin + py) * a.Win + px) * ld + nn;
-    }
-    if constexpr (EPI >= 2) {
-      const bool join = outp == a.out0;   // split data gradients accumulate into out0 only
-      float prev[4], yv[4], zv[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) prev[e] = (join && ok[e]) ? outp[off[e]] : 0.f;
-      if constexpr (EPI == 3) {
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * qr + ii;   // accumulator row m = (i & 3) + 8 (i >> 2) + 4 kh: tile row i >> 2, tile column (i & 3) + 4 kh
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          yv[e] = ok[e] ? a.bnb.y[off[e]] : 0.f;
-          zv[e] = ok[e] ? a.bnb.act[off[e]] : 0.f;
+          const int py = 2 * (i >> 2) + (e >> 1), px = 2 * (i & 3) + (e & 1);
+          const bool ok = ybase + py < a.Hin && xlane + px < a.Win;
+          off[4 * ii + e] = ok ? lane_base : WN_OOB;
+          soff[4 * ii + e] = tile_base + py * row4 + px * ld4;
         }
       }
+      if constexpr (EPI >= 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (ok[e]) {
-          const float v = y[e] + prev[e];
-          if constexpr (EPI == 3) {
-            const float g = zv[e] > 0.f ? v : 0.f;
-            s1 += g;
-            s2 += g * ((yv[e] - b_mu) * b_is);
-          }
-          outp[off[e]] = v;
+        for (int x = 0; x < 16; ++x)
+          prev[x] = join ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rso, off[x], soff[x], 0)) : 0.f;
+      }
+      if constexpr (EPI == 1 || EPI == 3) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) yv[x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsy, off[x], soff[x], 0));
+      }
+      if constexpr (EPI == 3) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) zv[x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsz, off[x], soff[x], 0));
+      }
+      float y[16];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = 4 * qr + ii;
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t0[j] = acc[0 + j][i] + acc[4 + j][i] + acc[8 + j][i];
+          t1[j] = acc[4 + j][i] - acc[8 + j][i] - acc[12 + j][i];
         }
-    } else if constexpr (EPI == 1) {
-      float yv[4];
+        y[4 * ii + 0] = t0[0] + t0[1] + t0[2];
+        y[4 * ii + 1] = t0[1] - t0[2] - t0[3];
+        y[4 * ii + 2] = t1[0] + t1[1] + t1[2];
+        y[4 * ii + 3] = t1[1] - t1[2] - t1[3];
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) yv[e] = ok[e] ? a.bnb.y[off[e]] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (ok[e]) {
-          const float g = (yv[e] * b_sc + b_sh) > 0.f ? y[e] : 0.f;
+      for (int x = 0; x < 16; ++x) {
+        const bool ok = off[x] != WN_OOB;
+        float v = y[x];
+        if constexpr (EPI >= 2) v += prev[x];
+        if constexpr (EPI == 3) {
+          const float g = (ok && zv[x] > 0.f) ? v : 0.f;
           s1 += g;
-          s2 += g * ((yv[e] - b_mu) * b_is);
-          outp[off[e]] = y[e];
+          s2 += g * ((yv[x] - b_mu) * b_is);
+        } else if constexpr (EPI == 1) {
+          const float g = (ok && (yv[x] * b_sc + b_sh) > 0.f) ? v : 0.f;
+          s1 += g;
+          s2 += g * ((yv[x] - b_mu) * b_is);
+        } else if constexpr (EPI == 0) {
+          const float g = ok ? v : 0.f;
+          s1 += g;
+          s2 += g * g;
         }
-    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rso, off[x], soff[x], 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (ok[e]) {
-          s1 += y[e];
-          s2 += y[e] * y[e];
-          outp[off[e]] = y[e];
-        }
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+    if (a.stats != nullptr) {
+      const float u1 = s1 + __shfl_xor(s1, 32, 64);
+      const float u2 = s2 + __shfl_xor(s2, 32, 64);
+      if (kh == 0) {
+        red[wm * 64 + 32 * wn + r] = u1;
+        red[128 + wm * 64 + 32 * wn + r] = u2;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = red[which * 128 + c] + red[which * 128 + 64 + c];
+      }
+      // the next step's barrier orders these reads of `red` before the next tile's writes
     }
-  }
-  if (a.stats != nullptr) {
-    __syncthreads();   // all waves done with the operand images
-    float* red = lds;  // [2][2 m-waves][64]
-    const float u1 = s1 + __shfl_xor(s1, 32, 64);
-    const float u2 = s2 + __shfl_xor(s2, 32, 64);
-    if (kh == 0) {
-      red[wm * 64 + 32 * wn + r] = u1;
-      red[128 + wm * 64 + 32 * wn + r] = u2;
+  };
+
+  // Structured as tiles x chunk pairs (the chunk count is even: host check), not as one flat step loop with a
+  // conditional epilogue: across a two-way join hipcc no longer keeps the 256 accumulators in place (hundreds of spills).
+  // The staging contexts above run ahead across the tile boundaries regardless.
+  for (int round = 0; round < my_tiles; ++round) {
+    for (int c = 0; c < nch; c += 2) {
+      // every wave has waited for its own weight planes (vmcnt in step / prologue) and waits here for its own V writes
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      step(S0{});
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      step(S1{});
     }
-    __syncthreads();
-    if (tid < 128) {
-      const int which = tid >> 6, c = tid & 63;
-      a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = red[which * 128 + c] + red[which * 128 + 64 + c];
-    }
+    epilogue(round);
   }
 }
 
@@ -397,7 +524,7 @@ extern "C" int dt_winograd_weights(const float* w_hwio, float* u, int Cin, int C
 extern "C" int dt_conv2d_winograd_supported(const dt_conv_desc* d) {
   if (d == nullptr) return 0;
   if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->mode0 == 2) return 0;
-  if ((d->C0 % 8) != 0 || (d->C1 % 8) != 0 || (d->Cout % 64) != 0 || d->C0 > WN_TF_MAXC) return 0;
+  if ((d->C0 % 8) != 0 || (d->C1 % 8) != 0 || ((d->C0 + d->C1) % 16) != 0 || (d->Cout % 64) != 0 || d->C0 > WN_TF_MAXC) return 0;
   if (d->cout_split != 0 && (d->cout_split % 64) != 0) return 0;
   return 1;
 }
@@ -427,16 +554,23 @@ int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* s
   DT_REQUIRE(b0 < 0x80000000ull && b1 < 0x80000000ull, "conv_winograd: a source of 2 GiB or more (use the direct kernel)");
   a.bytes0 = (unsigned)b0;
   a.bytes1 = (unsigned)b1;
+  const size_t opx = (size_t)d->B * d->Ho * d->Wo * 4;
+  const size_t ob0 = opx * (d->cout_split ? d->cout_split : d->Cout), ob1 = opx * (d->cout_split ? d->Cout - d->cout_split : 0);
+  DT_REQUIRE(ob0 < 0x80000000ull && ob1 < 0x80000000ull, "conv_winograd: an output of 2 GiB or more (use the direct kernel)");
+  a.obytes0 = (unsigned)ob0;
+  a.ubytes = (unsigned)((size_t)16 * (d->C0 + d->C1) * d->Cout * 4);
+  a.obytes1 = (unsigned)ob1;
   const bool bnb = a.bnb.y != nullptr, join = d->accumulate != 0;
   DT_REQUIRE(!bnb || stats != nullptr, "conv_winograd: fused BatchNorm-backward sums need the stats buffer");
   DT_REQUIRE(!(in_scale != nullptr && bnb), "conv_winograd: no input transform on the BatchNorm-backward form");
-  dim3 g((unsigned)((long)a.P * a.n_tiles)), blk(256);
-  if (in_scale != nullptr && join) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 2>), g, blk, 0, st, a);
-  else if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 0>), g, blk, 0, st, a);
-  else if (!bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 0>), g, blk, 0, st, a);
-  else if (bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 1>), g, blk, 0, st, a);
-  else if (!bnb && join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 2>), g, blk, 0, st, a);
-  else hipLaunchKernelGGL((conv3x3_wino_kernel<false, 3>), g, blk, 0, st, a);
+  const int total = a.P * a.n_tiles;
+  dim3 g((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)), blk(256);   // persistent: one workgroup per CU
+  if (in_scale != nullptr && join) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 2>), g, blk, 0, st, a, total);
+  else if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 0>), g, blk, 0, st, a, total);
+  else if (!bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 0>), g, blk, 0, st, a, total);
+  else if (bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 1>), g, blk, 0, st, a, total);
+  else if (!bnb && join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 2>), g, blk, 0, st, a, total);
+  else hipLaunchKernelGGL((conv3x3_wino_kernel<false, 3>), g, blk, 0, st, a, total);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -28,7 +28,9 @@ def nchw(t):
 CASES = [  # B, H, W (stored size of source 0), C0, C1, mode0, Cout, split, transform
     (2, 32, 32, 64, 0, 0, 64, 0, False), (1, 34, 70, 512, 0, 0, 64, 0, True), (3, 17, 33, 32, 0, 0, 128, 0, False),
     (2, 16, 20, 64, 32, 1, 128, 0, True), (2, 16, 24, 128, 64, 1, 64, 0, False), (2, 40, 48, 64, 0, 0, 192, 64, False),
-    (2, 16, 16, 8, 0, 0, 64, 0, False), (1, 5, 7, 16, 8, 0, 64, 0, True)]
+    (2, 16, 16, 16, 0, 0, 64, 0, False), (1, 5, 7, 16, 16, 0, 64, 0, True),
+    # persistent workgroups over several rounds (490 and 735 tiles on 256 CUs), ragged edges, tile-boundary prefetch
+    (5, 100, 100, 16, 0, 0, 128, 0, True), (5, 50, 50, 16, 16, 1, 192, 64, False)]
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,split,tf", CASES)
