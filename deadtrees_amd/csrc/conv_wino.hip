@@ -478,10 +478,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
 }
 
 // ---------------------------------------------------------------- U = G g G^T in the kernel's LDS image order
-__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout) {
-  // one thread per (input-channel quad, output channel): 9 x 4 weights in, 16 float4 out
-  const int co = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int cq = blockIdx.y * 4 + (threadIdx.x >> 6);
+// one thread per (input-channel quad, output channel): 9 x 4 weights in, 16 float4 out
+__device__ __forceinline__ void wino_weights_tile(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout,
+                                                  int co, int cq) {
   if (co >= Cout || 4 * cq >= Cin) return;
   f32x4 g[9];
 #pragma unroll
@@ -513,10 +512,43 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout) {
+  wino_weights_tile(w, u, Cin, Cout, blockIdx.x * 64 + (threadIdx.x & 63), blockIdx.y * 4 + (threadIdx.x >> 6));
+}
+
 extern "C" int dt_winograd_weights(const float* w_hwio, float* u, int Cin, int Cout, void* stream) {
   DT_REQUIRE(w_hwio && u && Cin > 0 && Cout > 0 && (Cin % 8) == 0, "winograd_weights: Cin must be a multiple of 8");
   dim3 grid(dt_cdiv(Cout, 64), dt_cdiv(Cin / 4, 4));
   hipLaunchKernelGGL(wino_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, w_hwio, u, Cin, Cout);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// every eligible layer of a network in ONE launch (the per-layer kernel is ~5 us and there are ~60 images per step):
+// table row l = (w_off, u_off, Cin, Cout, first_block); w_off into `weights` (the flat parameter buffer, or its
+// flipped / transposed data-gradient image from dt_weight_images mode 0 with Cin / Cout swapped), u_off into `u`
+__global__ void wino_weight_images_kernel(const float* __restrict__ weights, float* __restrict__ u,
+                                          const int32_t* __restrict__ table, int n_layers) {
+  __shared__ int32_t row[5];
+  if (threadIdx.x == 0) {
+    int l = 0;
+    while (l + 1 < n_layers && table[(l + 1) * 5 + 4] <= (int)blockIdx.x) ++l;   // <= 64 layers: linear scan
+#pragma unroll
+    for (int k = 0; k < 5; ++k) row[k] = table[l * 5 + k];
+  }
+  __syncthreads();
+  const int Cin = row[2], Cout = row[3];
+  const int t = (int)blockIdx.x - row[4];
+  const int cob = (Cout + 63) / 64;
+  wino_weights_tile(weights + row[0], u + row[1], Cin, Cout, (t % cob) * 64 + (threadIdx.x & 63),
+                    (t / cob) * 4 + (threadIdx.x >> 6));
+}
+
+extern "C" int dt_winograd_weight_images(const float* weights, float* u, const int32_t* table, int n_layers,
+                                         int total_blocks, void* stream) {
+  DT_REQUIRE(weights && u && table && n_layers > 0 && total_blocks > 0, "winograd_weight_images: bad args");
+  hipLaunchKernelGGL(wino_weight_images_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, weights,
+                     u, table, n_layers);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -583,4 +615,17 @@ extern "C" int dt_conv2d_winograd(const dt_conv_desc* d, const float* src0, cons
   DT_REQUIRE(d->cout_split == 0 || out1, "conv_winograd: out1 missing");
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_winograd: in_scale/in_shift must come together");
   return dt_conv_wino_launch(d, src0, src1, u, out0, out1, stats, in_scale, in_shift, nullptr, (hipStream_t)stream);
+}
+
+// data gradient with the BatchNorm-backward sums of the layer the gradient belongs to fused into the epilogue: the
+// Winograd form of dt_conv2d_bn_bwd (same arguments; `u` = dt_winograd_weights of the flipped / transposed weights)
+extern "C" int dt_conv2d_winograd_bn_bwd(const dt_conv_desc* d, const float* src0, const float* u, float* out0,
+                                         float* red, const dt_bn_bwd_fuse* fuse, void* stream) {
+  DT_REQUIRE(d && src0 && u && out0 && fuse && red && fuse->y && fuse->mean && fuse->invstd, "conv_winograd_bn_bwd: null pointer");
+  DT_REQUIRE(fuse->act != nullptr || (fuse->act_scale && fuse->act_shift),
+             "conv_winograd_bn_bwd: give the stored activation or the scale/shift of a virtual one");
+  DT_REQUIRE(d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0, "conv_winograd_bn_bwd: plain 3x3 stride-1 data gradients only");
+  DT_REQUIRE((d->accumulate != 0) == (fuse->act != nullptr),
+             "conv_winograd_bn_bwd: gradient joins (accumulate) go with a stored activation, plain stores with a virtual one");
+  return dt_conv_wino_launch(d, src0, nullptr, u, out0, nullptr, red, nullptr, nullptr, fuse, (hipStream_t)stream);
 }

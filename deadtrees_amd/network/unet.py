@@ -56,6 +56,7 @@ class UNetEngine:
         # when a list: every dt_conv2d launch appends (kernel name, algorithmic FLOPs, start, end events)
         self.profile: Optional[list] = None
         self._weights_epoch = 0
+        self._u_all = self._ud_all = None     # Winograd weight images of the current forward / backward pass
         # side-stream weight gradients: measured SLOWER on MI355X (485 vs 528 tiles/s fp32, 1505 vs 1566 bf16): the
         # co-resident wgrad / dgrad workgroups halve each other's occupancy and share the matrix pipe — off by default
         self.overlap_wgrad = False
@@ -65,6 +66,9 @@ class UNetEngine:
         # epilogue); the bf16 path keeps it (its join epilogue is LDS-staged, +0.5 %).  Kernel support stays tested.
         self.fuse_join_fp32 = False
         self._fuse_bn = not os.environ.get("DT_NO_BN_FUSE")   # A/B switch for the plain fused reductions
+        # fp32 3x3 stride-1 layers (forward + data gradient) on the Winograd F(2x2,3x3) kernel where its shape conditions
+        # hold (conv_wino.hip: 1.6-2.0x the direct kernel per layer); DT_FP32_WINOGRAD=0 keeps the exact-fma direct kernel
+        self.winograd = os.environ.get("DT_FP32_WINOGRAD", "1") != "0"
         # when a dict: the bf16 training pass stores a copy of every intermediate tensor it produces under the
         # names of oracle/unet_bf16_ref.py (teacher-forced parity test); None in production
         self.trace: Optional[dict] = None
@@ -94,14 +98,31 @@ class UNetEngine:
         tf = "true" if transformed else "false"
         return f"conv_fwd_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, {zi}, {tf}>"
 
-    def _conv(self, desc, src0, src1, w, out0, out1=None, stats=None, in_ss=None):
+    def _use_wino(self, desc, u) -> bool:
+        return u is not None and bool(self.lib.dt_conv2d_winograd_supported(C.byref(desc)))
+
+    def _stat_rows(self, desc, u=None) -> int:
+        """rows of the BatchNorm partial-statistics buffer the convolution launch for `desc` writes"""
+        P = (self.lib.dt_conv2d_winograd_stat_rows if self._use_wino(desc, u) else self.lib.dt_conv2d_stat_rows)(C.byref(desc))
+        if P <= 0:
+            raise RuntimeError(f"dt_conv2d_stat_rows: {self.lib.dt_last_error().decode()}")
+        return P
+
+    def _conv(self, desc, src0, src1, w, out0, out1=None, stats=None, in_ss=None, u=None):
+        """u: the layer's Winograd weight image (or None): used when the kernel supports the descriptor"""
         prof = self.profile
+        wino = self._use_wino(desc, u)
         if prof is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(self.lib.dt_conv2d(C.byref(desc), _p(src0), _p(src1), _p(w), _p(out0), _p(out1), _p(stats),
-                                      _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
-                                      _stream()), "dt_conv2d")
+        if wino:
+            _lib.check(self.lib.dt_conv2d_winograd(C.byref(desc), _p(src0), _p(src1), _p(u), _p(out0), _p(out1),
+                                                   _p(stats), _p(in_ss[0]) if in_ss else None,
+                                                   _p(in_ss[1]) if in_ss else None, _stream()), "dt_conv2d_winograd")
+        else:
+            _lib.check(self.lib.dt_conv2d(C.byref(desc), _p(src0), _p(src1), _p(w), _p(out0), _p(out1), _p(stats),
+                                          _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
+                                          _stream()), "dt_conv2d")
         if prof is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -113,7 +134,65 @@ class UNetEngine:
             nbytes = 4.0 * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
                                      desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
                 4.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
-            prof.append((self._conv_kernel_name(desc, in_ss is not None), flops, e0, e1, nbytes))
+            name = self._wino_kernel_name(in_ss is not None, 2 if desc.accumulate else 0) if wino else \
+                self._conv_kernel_name(desc, in_ss is not None)
+            prof.append((name, flops, e0, e1, nbytes))
+
+    @staticmethod
+    def _wino_kernel_name(transformed: bool, epi: int) -> str:
+        return f"conv3x3_wino_kernel<{'true' if transformed else 'false'}, {epi}>"
+
+    # ------------------------------------------------------------------ Winograd weight images (conv_wino.hip)
+    def _wino_table(self, device, dgrad: bool):
+        """(device table, rows, blocks, total floats, {conv key: offset}) of the layers whose forward conv (dgrad False)
+        or stride-1 data gradient (dgrad True: Cin / Cout swapped, read from the dt_weight_images mode-0 buffer) can run
+        on the Winograd kernel: 3x3 stride 1 pad 1, input channels a multiple of 16, output channels a multiple of 64"""
+        key = ("wino", bool(dgrad), str(device))
+        if not hasattr(self, "_tables"):
+            self._tables = {}
+        tab = self._tables.get(key)
+        if tab is None:
+            rows, blocks, off, offs = [], 0, 0, {}
+            for c in self.spec.convs:
+                if c is self.spec.stem or c is self.spec.head or c.k != 3 or c.stride != 1 or c.pad != 1:
+                    continue
+                cin, cout = (c.cout, c.cin) if dgrad else (c.cin, c.cout)
+                if cin % 16 or cout % 64:
+                    continue
+                rows.append([c.w_off, off, cin, cout, blocks])
+                offs[c.key] = (off, 16 * cin * cout)
+                blocks += ((cout + 63) // 64) * ((cin // 4 + 3) // 4)
+                off += 16 * cin * cout
+            tab = (torch.tensor(rows, dtype=torch.int32).to(device) if rows else None, len(rows), blocks, off, offs)
+            self._tables[key] = tab
+        return tab
+
+    def _wino_images(self, weights: torch.Tensor, name: str, dgrad: bool):
+        tab, n, blocks, total, _ = self._wino_table(weights.device, dgrad)
+        if n == 0:
+            return None
+        buf = self._buf(name, total, device=weights.device)
+        _lib.check(self.lib.dt_winograd_weight_images(_p(weights), _p(buf), _p(tab), n, blocks, _stream()),
+                   "dt_winograd_weight_images")
+        return buf
+
+    def _wino_fwd_weights(self, params: torch.Tensor):
+        """forward images of every eligible layer, rebuilt when the flat parameter buffer changed (one launch)"""
+        if not self.winograd:
+            return None
+        key = (params.data_ptr(), params._version, self._weights_epoch)
+        if self._ws.get("wino_u_key") != key:
+            self._ws["wino_u_val"] = self._wino_images(params, "wino_u", False)
+            self._ws["wino_u_key"] = key
+        return self._ws["wino_u_val"]
+
+    def _u(self, c: ConvSpec, dgrad: bool = False):
+        """the Winograd image of conv c (forward / data gradient) or None"""
+        buf = self._ud_all if dgrad else self._u_all
+        if buf is None:
+            return None
+        ent = self._wino_table(buf.device, dgrad)[4].get(c.key)
+        return None if ent is None else buf[ent[0]:ent[0] + ent[1]]
 
     # ------------------------------------------------------------------ forward units
     def _ss(self, c: ConvSpec, bnws):
@@ -144,17 +223,16 @@ class UNetEngine:
         beta = params[c.b_off:c.b_off + c.cout]
         rmean = bnstate[2 * c.bn_off: 2 * c.bn_off + c.cout]
         rvar = bnstate[2 * c.bn_off + c.cout: 2 * c.bn_off + 2 * c.cout]
+        u = self._u(c)
         if training:
-            P = self.lib.dt_conv2d_stat_rows(C.byref(desc))
-            if P <= 0:
-                raise RuntimeError(f"dt_conv2d_stat_rows: {self.lib.dt_last_error().decode()}")
+            P = self._stat_rows(desc, u)
             stats = self._buf("bn_stats", self.lib.dt_bn_stats_floats(P, c.cout), device=dev)
-            self._conv(desc, src0, src1, w, y, None, stats, in_ss)
+            self._conv(desc, src0, src1, w, y, None, stats, in_ss, u=u)
             _lib.check(self.lib.dt_bn_finalize(_p(stats), P, c.cout, float(B * Ho * Wo), _p(gamma), _p(beta),
                                                BN_EPS, BN_MOMENTUM, _p(rmean), _p(rvar), _p(mean), _p(invstd),
                                                _p(scale), _p(shift), _stream()), "dt_bn_finalize")
         else:
-            self._conv(desc, src0, src1, w, y, None, None, in_ss)
+            self._conv(desc, src0, src1, w, y, None, None, in_ss, u=u)
             _lib.check(self.lib.dt_bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), BN_EPS, c.cout,
                                                   _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
             if save_stats:   # a backward pass may follow (frozen-BatchNorm fine-tuning): xhat uses the running stats
@@ -195,6 +273,7 @@ class UNetEngine:
         st = _stream()
         lib = self.lib
         sv = _Saved() if save else None
+        self._u_all = self._wino_fwd_weights(params)
         bnws = self._buf("bnws", 4 * sp.n_bn_channels, device=dev)
         if save:
             # mean/invstd are needed by backward: keep a private copy target per forward
@@ -921,7 +1000,9 @@ class UNetEngine:
         assert c.stride == 1 and c.cin == Cc and tuple(y.shape) == tuple(out0.shape)
         wd = self._wd_all[c.w_off:c.w_off + c.w_size]
         desc = self._desc(B, H, W, c.cout, 0, 0, H, W, c.cin, c.k, 1, c.k - 1 - c.pad, 0, 0 if act is None else 1)
-        P = self.lib.dt_conv2d_stat_rows(C.byref(desc))
+        ud = self._u(c, dgrad=True)
+        wino = self._use_wino(desc, ud)
+        P = self._stat_rows(desc, ud)
         red = self._buf("bn_red_fused", self.lib.dt_bn_stats_floats(P, Cc), device=dy.device)
         nb = self.spec.n_bn_channels
         asc, ash = self._ss(bn_conv, bnws) if act is None else (None, None)
@@ -931,15 +1012,20 @@ class UNetEngine:
         if prof is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(self.lib.dt_conv2d_bn_bwd(C.byref(desc), _p(dy), _p(wd), _p(out0), _p(red), C.byref(fuse),
-                                             _stream()), "dt_conv2d_bn_bwd")
+        if wino:
+            _lib.check(self.lib.dt_conv2d_winograd_bn_bwd(C.byref(desc), _p(dy), _p(ud), _p(out0), _p(red),
+                                                          C.byref(fuse), _stream()), "dt_conv2d_winograd_bn_bwd")
+        else:
+            _lib.check(self.lib.dt_conv2d_bn_bwd(C.byref(desc), _p(dy), _p(wd), _p(out0), _p(red), C.byref(fuse),
+                                                 _stream()), "dt_conv2d_bn_bwd")
         if prof is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             flops = 2.0 * desc.ksize ** 2 * desc.C0 * desc.Cout * desc.Ho * desc.Wo * desc.B
             nbytes = 4.0 * desc.B * desc.Ho * desc.Wo * (desc.C0 + (2 if act is None else 4) * desc.Cout) + \
                 4.0 * desc.ksize ** 2 * desc.C0 * desc.Cout
-            prof.append((self._conv_kernel_name(desc, False), flops, e0, e1, nbytes))
+            name = self._wino_kernel_name(False, 1 if act is None else 3) if wino else self._conv_kernel_name(desc, False)
+            prof.append((name, flops, e0, e1, nbytes))
         return red, P
 
     def _dgrad(self, c: ConvSpec, params, dy, B, Hin, Win, out0, out1=None, split=0, acc=False):
@@ -952,7 +1038,7 @@ class UNetEngine:
         else:
             assert Hin == 2 * Ho and Win == 2 * Wo
             desc = self._desc(B, Hin, Win, c.cout, 0, 2, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
-        self._conv(desc, dy, None, wd, out0, out1, None)
+        self._conv(desc, dy, None, wd, out0, out1, None, u=self._u(c, dgrad=True) if c.stride == 1 else None)
 
     def _backward_resunet_block(self, blk, d, g, params, grads, bnws, B, Hh, Ww, skip_grads, skip_slot):
         """reverse of one ResUnet decoder block (forward: see the decoder loop): g = gradient of the block output
@@ -1015,6 +1101,7 @@ class UNetEngine:
         # data-gradient weight images of every layer ([tap'][co][ci], taps reversed) in one launch
         self._wd_all = self._buf("wd_all", sp.n_params, device=dev)
         self._weight_images(params, self._wd_all, 0)
+        self._ud_all = self._wino_images(self._wd_all, "wino_ud", True) if self.winograd else None
 
         # ---- head
         hd = sp.head

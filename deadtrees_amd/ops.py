@@ -379,6 +379,22 @@ def conv2d_bn_bwd(src0, w_hwio, y, mean, invstd, act_scale=None, act_shift=None,
     return out, red[:2 * P * Cout].view(2, P, Cout)
 
 
+def conv2d_winograd_bn_bwd(src0, u, y, mean, invstd, act_scale=None, act_shift=None, act=None, join_into=None):
+    """Winograd form of conv2d_bn_bwd (u = winograd_weights of the data-gradient HWIO image) -> (out, red [2,P,Cout])"""
+    _gpu(src0, u, y, mean, invstd, act_scale, act_shift, act, join_into)
+    lib = _lib.load()
+    B, H, W, C0 = src0.shape
+    Cout = u.shape[3]
+    d = conv_desc(B, H, W, C0, 0, 0, Cout, 3, 1, 1, 0, 1 if join_into is not None else 0)
+    P = lib.dt_conv2d_winograd_stat_rows(C.byref(d))
+    red = torch.empty(lib.dt_bn_stats_floats(P, Cout), dtype=torch.float32, device=src0.device)
+    out = join_into if join_into is not None else torch.empty((B, H, W, Cout), dtype=torch.float32, device=src0.device)
+    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift), _p(act))
+    _lib.check(lib.dt_conv2d_winograd_bn_bwd(C.byref(d), _p(src0), _p(u), _p(out), _p(red), C.byref(fuse), _st()),
+               "dt_conv2d_winograd_bn_bwd")
+    return out, red[:2 * P * Cout].view(2, P, Cout)
+
+
 def conv2d_bf16_bn_bwd(src0, w_packed, cout, y, mean, invstd, act_scale=None, act_shift=None, act=None,
                        join_into=None):
     """bf16 twin of conv2d_bn_bwd (src0, y, act, join_into bf16 NHWC; w_packed from pack_weights_bf16)

@@ -85,6 +85,11 @@ int dt_conv2d_winograd_stat_rows(const dt_conv_desc* d);
 int dt_winograd_weights(const float* w_hwio, float* u, int Cin, int Cout, void* stream);
 int dt_conv2d_winograd(const dt_conv_desc* d, const float* src0, const float* src1, const float* u, float* out0,
                        float* out1, float* stats, const float* in_scale, const float* in_shift, void* stream);
+/* all eligible layers in one launch: int32 table rows (w_off, u_off, Cin, Cout, first_block), blocks of a layer =
+ * ceil(Cout/64) * ceil(Cin/16); `weights` = the flat parameter buffer (forward images) or its dt_weight_images mode-0
+ * image with Cin/Cout swapped (data-gradient images). */
+int dt_winograd_weight_images(const float* weights, float* u, const int32_t* table, int n_layers, int total_blocks,
+                              void* stream);
 
 /* wd[kh'][kw'][co][ci] = w[K-1-kh'][K-1-kw'][ci][co]: weights of the data-gradient convolution. */
 int dt_weight_flip_transpose(const float* w_hwio, float* wd, int ksize, int Cin, int Cout, void* stream);
@@ -192,6 +197,9 @@ typedef struct dt_bn_bwd_fuse {
 } dt_bn_bwd_fuse;
 int dt_conv2d_bn_bwd(const dt_conv_desc* desc, const float* src0, const float* w, float* out0, float* red,
                      const dt_bn_bwd_fuse* fuse, void* stream);
+/* Winograd form of dt_conv2d_bn_bwd: same arguments, u = dt_winograd_weights of the flipped / transposed weights. */
+int dt_conv2d_winograd_bn_bwd(const dt_conv_desc* d, const float* src0, const float* u, float* out0, float* red,
+                              const dt_bn_bwd_fuse* fuse, void* stream);
 
 /* ------------------------------------------------------------------ segmentation head (K11,K12,K19) */
 /* logits[B,K,H,W] (NCHW) = conv3x3(x[B,H,W,Cin], w[K][3][3][Cin]) + bias; optional uint8/int64 argmax

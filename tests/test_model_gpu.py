@@ -111,7 +111,8 @@ def test_forward_parity_at_benchmark_tile_size_with_flip_report(mode):
 
 @pytest.mark.parametrize("C,K,names", [(3, 2, ("GDICE", "FOCAL")), (4, 3, ("DICE", "FOCAL", "BOUNDARY")),
                                        (3, 3, ("GWDICE", "FOCAL"))])
-def test_train_step_gradient_parity(C, K, names):
+@pytest.mark.parametrize("winograd", [False, True])
+def test_train_step_gradient_parity(C, K, names, winograd):
     """loss + every parameter gradient of one training step vs the oracle (RGB / RGBN, 2 / 3 classes, each dice
     flavour, boundary loss on device-built distance maps).
 
@@ -126,6 +127,12 @@ def test_train_step_gradient_parity(C, K, names):
     from oracle.losses_ref import dist_map, one_hot
     B, H, W = 2, 128, 128
     ref, m = _pair(C, K)
+    # winograd False: every convolution an exact fp32 fma chain (direct kernels) -> the bounds the round-1 path was held
+    # to.  True (the default engine): the 3x3 stride-1 layers run as Winograd F(2x2,3x3), ~1e-6 relative per layer
+    # instead of ~3e-7, which flips a few more ReLU masks of this ill-conditioned end-to-end gradient: 8x / 3x the fp32
+    # CPU oracle's own distance from fp64 instead of 4x / 2x.
+    m.engine.winograd = winograd
+    per_tensor, overall = (8.0, 3.0) if winograd else (4.0, 2.0)
     ref64 = copy.deepcopy(ref).double()
     img, mask = _synth(B, H, W, C, K)
     dist = None
@@ -161,11 +168,11 @@ def test_train_step_gradient_parity(C, K, names):
         n = float(g.norm()) + 1e-30
         eh = float((grads[k].double() - g).norm())
         er = float((g32[k].double() - g).norm())
-        assert eh <= 4.0 * er + 1e-4 * n, (k, eh / n, er / n)   # per tensor: 4x the fp32 oracle's own error
+        assert eh <= per_tensor * er + 1e-4 * n, (k, eh / n, er / n)   # per tensor: N x the fp32 oracle's own error
         tot_hip += eh ** 2
         tot_ref += er ** 2
         tot += n ** 2
-    assert tot_hip ** 0.5 <= 2.0 * tot_ref ** 0.5 + 1e-5 * tot ** 0.5, (tot_hip, tot_ref, tot)
+    assert tot_hip ** 0.5 <= overall * tot_ref ** 0.5 + 1e-5 * tot ** 0.5, (tot_hip, tot_ref, tot)
     # BN running statistics were updated like torch's
     sd_ref, sd = ref.state_dict(), m.state_dict()
     for k in sd_ref:

@@ -81,3 +81,61 @@ def test_winograd_weight_transform():
     u = ops.winograd_weights(w.float().to(DEV)).cpu().double()   # [16][Cin/8][2][Cout][4]
     got = u.permute(0, 1, 2, 4, 3).reshape(16, Cin, Cout).reshape(4, 4, Cin, Cout)
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("join", [False, True])
+def test_winograd_fused_bn_backward_sums_match_the_direct_kernel(join):
+    """dt_conv2d_winograd_bn_bwd against dt_conv2d_bn_bwd: the gradient within the Winograd tolerance, the
+    BatchNorm-backward partial sums (virtual activation / stored activation + gradient join) equal per channel; ragged
+    map, several rounds of the persistent workgroups."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7 + join)
+    B, H, W, Cin, Cout = 3, 100, 84, 32, 128
+    dy = torch.randn((B, H, W, Cin), generator=g).to(DEV)
+    w = (torch.randn((3, 3, Cin, Cout), generator=g) * 0.05).to(DEV)
+    y = (torch.randn((B, H, W, Cout), generator=g) * 1.5 + 0.2).to(DEV)
+    mean = y.mean(dim=(0, 1, 2)).contiguous()
+    invstd = (1.0 / torch.sqrt(y.var(dim=(0, 1, 2), unbiased=False) + 1e-5)).contiguous()
+    sc = (1 + 0.2 * torch.randn(Cout, generator=g)).to(DEV)
+    sh = (0.2 * torch.randn(Cout, generator=g)).to(DEV)
+    act = torch.relu(y * sc + sh) if join else None
+    base = torch.randn((B, H, W, Cout), generator=g).to(DEV) if join else None
+    kw = dict(act=act, join_into=None) if join else dict(act_scale=sc, act_shift=sh)
+    if join:
+        kw["join_into"] = base.clone()
+    ref_out, ref_red = ops.conv2d_bn_bwd(dy, w, y, mean, invstd, **kw)
+    if join:
+        kw["join_into"] = base.clone()
+    out, red = ops.conv2d_winograd_bn_bwd(dy, ops.winograd_weights(w), y, mean, invstd, **kw)
+    scale = float(ref_out.abs().max())
+    assert float((out - ref_out).abs().max()) <= 1e-5 * scale
+    a, b = red.double().sum(1).cpu(), ref_red.double().sum(1).cpu()
+    # a gradient within 1e-5 of zero may fall on the other side of nothing (the mask comes from y, not from the result)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
+
+def test_winograd_weight_images_of_a_network_match_the_per_layer_transform():
+    """dt_winograd_weight_images (all eligible layers, forward and data-gradient images, one launch each) against
+    dt_winograd_weights layer by layer"""
+    from deadtrees_amd.network.unet import UNetHIP
+    ops = _ops()
+    m = UNetHIP().to(DEV)
+    m.reset_parameters(seed=1)
+    eng, params = m.engine, m.flat_params.detach()
+    eng.winograd = True
+    u_all = eng._wino_images(params, "t_u", False)
+    wd_all = torch.empty_like(params)
+    eng._weight_images(params, wd_all, 0)
+    ud_all = eng._wino_images(wd_all, "t_ud", True)
+    n = 0
+    for dgrad, buf, src in ((False, u_all, params), (True, ud_all, wd_all)):
+        offs = eng._wino_table(params.device, dgrad)[4]
+        for c in eng.spec.convs:
+            if c.key not in offs:
+                continue
+            cin, cout = (c.cout, c.cin) if dgrad else (c.cin, c.cout)
+            want = ops.winograd_weights(src[c.w_off:c.w_off + c.w_size].view(3, 3, cin, cout))
+            off, size = offs[c.key]
+            assert torch.equal(buf[off:off + size], want.reshape(-1)), (c.key, dgrad)
+            n += 1
+    assert n >= 50
