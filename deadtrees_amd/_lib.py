@@ -57,6 +57,9 @@ SIGNATURES = {
     "dt_conv2d_winograd_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),
     "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),
+    "dt_conv2d_wgrad_winograd_supported": (C.c_int, [_P]),
+    "dt_conv2d_wgrad_winograd_workspace": (SZ, [_P]),
+    "dt_conv2d_wgrad_winograd": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),
     "dt_bn_stats_floats": (I64, [C.c_int, C.c_int]),
     "dt_bn_bwd_red_floats": (I64, [I64, C.c_int]),
     "dt_bn_finalize": (C.c_int, [c_f, C.c_int, C.c_int, F64, c_f, c_f, F32, F32, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),

@@ -66,6 +66,25 @@ def conv2d(src0, w_hwio, k, stride, pad, src1=None, mode0=0, split=0, out0=None,
     return out0, out1, stats
 
 
+def conv2d_wgrad_winograd(src0, dy, src1=None, mode0=0, in_scale=None, in_shift=None):
+    """3x3 stride-1 pad-1 weight gradient through dt_conv2d_wgrad_winograd -> dw HWIO"""
+    _gpu(src0, src1, dy)
+    lib = _lib.load()
+    B, C0 = src0.shape[0], src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    Hin, Win = (src0.shape[1], src0.shape[2]) if mode0 == 0 else (2 * src0.shape[1], 2 * src0.shape[2])
+    Cout = dy.shape[-1]
+    d = conv_desc(B, Hin, Win, C0, C1, mode0, Cout, 3, 1, 1)
+    if not lib.dt_conv2d_wgrad_winograd_supported(C.byref(d)):
+        raise ValueError("layer shape not supported by the Winograd weight-gradient kernel")
+    nbytes = lib.dt_conv2d_wgrad_winograd_workspace(C.byref(d))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dy.device)
+    dw = torch.empty((3, 3, C0 + C1, Cout), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.dt_conv2d_wgrad_winograd(C.byref(d), _p(src0), _p(src1), _p(dy.contiguous()), _p(dw), _p(ws), nbytes,
+                                            _p(in_scale), _p(in_shift), _st()), "dt_conv2d_wgrad_winograd")
+    return dw
+
+
 def winograd_weights(w_hwio):
     """U = G g G^T of a 3x3 HWIO weight in the Winograd kernel's image order [16][Cin/8][2][Cout][4]."""
     _gpu(w_hwio)

@@ -101,6 +101,13 @@ size_t dt_conv2d_wgrad_workspace(const dt_conv_desc* d);
 int dt_conv2d_wgrad(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy,
                     float* dw_hwio, float* workspace, size_t workspace_bytes, const float* in_scale,
                     const float* in_shift, void* stream);
+/* Winograd F(2x2,3x3) form of dt_conv2d_wgrad for 3x3 stride-1 pad-1 layers whose C0, C1 and Cout are multiples of 64
+ * (same arguments; 2.25x fewer multiplies, result within ~1e-6 relative of the direct form; deterministic). */
+int dt_conv2d_wgrad_winograd_supported(const dt_conv_desc* d);
+size_t dt_conv2d_wgrad_winograd_workspace(const dt_conv_desc* d);
+int dt_conv2d_wgrad_winograd(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy,
+                             float* dw_hwio, float* workspace, size_t workspace_bytes, const float* in_scale,
+                             const float* in_shift, void* stream);
 
 /* ------------------------------------------------------------------ BatchNorm / ReLU / residual (K2,K3,K8,K21) */
 /* stats[2][P][C] -> batch mean / biased var over `count` elements; writes mean, invstd, and the fused

@@ -59,6 +59,27 @@ for name, H, W, C0, C1, mode0, Cout in SHAPES:
             res[f"{kind}{'_tf' if tf else ''}_us"] = round(t * 1e6, 1)
             res[f"{kind}{'_tf' if tf else ''}_TF"] = round(flops / t / 1e12, 1)
         res[f"maxdiff{'_tf' if tf else ''}"] = float((out["direct"] - out["wino"]).abs().max() / out["direct"].abs().max())
+    if C0 % 64 == 0 and C1 % 64 == 0 and Cout % 64 == 0:
+        dy = torch.randn((B, Hin, Win, Cout), generator=g).cuda()
+        for kind in ("direct", "wino"):
+            def runw():
+                if kind == "direct":
+                    return ops.conv2d_wgrad(src0, dy, 3, 1, 1, src1=src1, mode0=mode0)
+                return ops.conv2d_wgrad_winograd(src0, dy, src1=src1, mode0=mode0)
+            out[kind] = runw()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    runw()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / reps * 1e-3)
+            res[f"wgrad_{kind}_us"] = round(min(ts) * 1e6, 1)
+            res[f"wgrad_{kind}_TF"] = round(flops / min(ts) / 1e12, 1)
+        res["wgrad_maxdiff"] = float((out["direct"] - out["wino"]).abs().max() / out["direct"].abs().max())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

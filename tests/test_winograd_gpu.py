@@ -139,3 +139,41 @@ def test_winograd_weight_images_of_a_network_match_the_per_layer_transform():
             assert torch.equal(buf[off:off + size], want.reshape(-1)), (c.key, dgrad)
             n += 1
     assert n >= 50
+
+
+WG_CASES = [  # B, H, W (stored size of source 0), C0, C1, mode0, Cout, transform
+    (2, 32, 32, 64, 0, 0, 64, False), (1, 34, 70, 128, 0, 0, 64, True), (3, 17, 33, 64, 0, 0, 128, False),
+    (2, 16, 20, 64, 64, 1, 128, True), (4, 64, 64, 64, 0, 0, 64, False), (2, 16, 16, 512, 0, 0, 512, False)]
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,tf", WG_CASES)
+def test_winograd_weight_gradient_matches_fp64_and_direct_kernel(B, H, W, C0, C1, mode0, Cout, tf):
+    """dt_conv2d_wgrad_winograd vs torch CPU fp64 autograd and vs dt_conv2d_wgrad: odd maps (half-empty edge tiles),
+    several splits with the two-stage reduction, upsample + concat + fused BatchNorm/ReLU on the input side"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 100 + H + C0 + Cout)
+    x = torch.randn((B, C0, H, W), generator=g)
+    Hin, Win = (H, W) if mode0 == 0 else (2 * H, 2 * W)
+    s1 = torch.randn((B, C1, Hin, Win), generator=g) if C1 else None
+    sc = 1 + 0.3 * torch.randn(C0, generator=g) if tf else None
+    sh = 0.3 * torch.randn(C0, generator=g) + 0.2 if tf else None
+    z = x.double()
+    if tf:
+        z = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]).double()
+    if mode0 == 1:
+        z = F.interpolate(z, scale_factor=2, mode="nearest")
+    xin = torch.cat([z, s1.double()], 1) if C1 else z
+    wt = (torch.randn((Cout, C0 + C1, 3, 3), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(xin, wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    want = wt.grad.permute(2, 3, 1, 0)      # HWIO
+    kw = dict(src1=nhwc(s1) if C1 else None, mode0=mode0, in_scale=sc.to(DEV) if tf else None,
+              in_shift=sh.to(DEV) if tf else None)
+    got = ops.conv2d_wgrad_winograd(nhwc(x), nhwc(dy), **kw).cpu().double()
+    direct = ops.conv2d_wgrad(nhwc(x), nhwc(dy), 3, 1, 1, **kw).cpu().double()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-5 * scale, float((got - want).abs().max()) / scale
+    assert float((direct - want).abs().max()) <= 2e-5 * scale
+    again = ops.conv2d_wgrad_winograd(nhwc(x), nhwc(dy), **kw).cpu().double()
+    assert torch.equal(again, got)          # fixed-order reduction: run-to-run bit-identical
