@@ -28,7 +28,7 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
     for name, (v, k) in fetch.items():
-        m = re.match(r"(?:void )?(conv_[a-z0-9_]+kernel(?:<[^>]*>)?)", name)
+        m = re.match(r"(?:void )?(conv[a-z0-9_]+kernel(?:<[^>]*>)?)", name)
         if not m:
             continue
         key = m.group(1)

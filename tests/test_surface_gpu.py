@@ -12,8 +12,12 @@ def _cfg(**kw):
     return default_network(**kw), default_training()
 
 
-def test_trainer_loss_trajectory_matches_oracle():
-    """4 optimiser steps (fwd, GDICE+FOCAL, bwd, clip 0.5, Adam 3e-4) on the same batch: loss curve vs oracle."""
+@pytest.mark.parametrize("winograd", [False, True])
+def test_trainer_loss_trajectory_matches_oracle(winograd):
+    """4 optimiser steps (fwd, GDICE+FOCAL, bwd, clip 0.5, Adam 3e-4) on the same batch: loss curve vs oracle.
+    Adam's first steps move every weight by +-lr, so a gradient within rounding of zero can go either way: the curves
+    separate slowly.  Direct kernels (exact fp32 fma chains): 2e-3 after the first step; the default engine (3x3
+    stride-1 layers as Winograd F(2x2,3x3), ~1e-6 relative per layer): 5e-3 (measured 2.2e-3 at step 3)."""
     from deadtrees_amd.data.synthetic import synth_batch
     from deadtrees_amd.network.unet import UNetHIP
     from deadtrees_amd.trainer import HipTrainer
@@ -23,6 +27,8 @@ def test_trainer_loss_trajectory_matches_oracle():
     m = UNetHIP()
     m.load_state_dict(ref.state_dict())
     m.to(DEV)
+    m.engine.winograd = winograd
+    later = 5e-3 if winograd else 2e-3
     img, mask = synth_batch(2, 128, 128, 3, 2, seed=7)
     rt = RefTrainer(ref)
     ht = HipTrainer(m)
@@ -30,7 +36,7 @@ def test_trainer_loss_trajectory_matches_oracle():
         lr_, gn_ = rt.step(img, mask)
         lh = float(ht.step(img.to(DEV), mask.to(DEV)))
         gn = float(ht.last["grad_norm"])
-        assert lh == pytest.approx(lr_, rel=2e-3 if step else 2e-5), (step, lh, lr_)
+        assert lh == pytest.approx(lr_, rel=later if step else 2e-5), (step, lh, lr_)
         assert gn == pytest.approx(gn_, rel=5e-2), (step, gn, gn_)
         assert int(ht.last["skipped"]) == 0
     # parameters moved the same way (Adam's first steps are +-lr: compare the bulk)
