@@ -20,5 +20,14 @@ Pinning status:
     un-vendored third-party package ``segmentation_models_pytorch>=0.2.1``
     (reference setup.py:47) which is absent here -> PARITY UNPINNED for the
     network topology; the oracle restates the published smp/torchvision
-    topology from torch primitives.
+    topology from torch primitives.  Round 2: the DECODER
+    wiring (nearest x2 upsample, cat([x, skip]), two Conv2dReLU per block, channel
+    arithmetic) is now pinned by execution — ``oracle/make_golden_resunet.py`` loads the
+    reference's in-tree twin of smp's decoder block (network/extra/resunet/decoder.py,
+    extra/modules.py; they import nothing that is absent) by file path and writes
+    ``tests/golden/resunet_decoder.npz``; the resnet34 ENCODER stays unpinned.
+  * ResUnet decoder (``resunet_ref.py``): pinned the same way (outputs, input gradients and
+    parameter gradients of the reference's own ``ResUnetDecoder``).
+  * bf16 training oracle (``unet_bf16_ref.py``): the fp32 restatement with bf16 roundings at
+    the HIP path's storage points; ``dtype=float32`` reproduces the fp32 oracle exactly.
 """
