@@ -558,6 +558,12 @@ extern "C" int dt_conv2d_winograd_supported(const dt_conv_desc* d) {
   if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->mode0 == 2) return 0;
   if ((d->C0 % 8) != 0 || (d->C1 % 8) != 0 || ((d->C0 + d->C1) % 16) != 0 || (d->Cout % 64) != 0 || d->C0 > WN_TF_MAXC) return 0;
   if (d->cout_split != 0 && (d->cout_split % 64) != 0) return 0;
+  // 32-bit byte offsets with 0x80000000 as the out-of-range marker: every operand below 2 GiB (else the direct kernel)
+  const size_t px0 = (size_t)d->B * (d->mode0 ? (d->Hin / 2) * (size_t)(d->Win / 2) : (size_t)d->Hin * d->Win);
+  if (px0 * d->C0 * 4 >= 0x80000000ull || (size_t)d->B * d->Hin * d->Win * d->C1 * 4 >= 0x80000000ull) return 0;
+  const size_t opx = (size_t)d->B * d->Ho * d->Wo * 4;
+  if (opx * (d->cout_split ? d->cout_split : d->Cout) >= 0x80000000ull) return 0;
+  if (d->cout_split && opx * (d->Cout - d->cout_split) >= 0x80000000ull) return 0;
   return 1;
 }
 

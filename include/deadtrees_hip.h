@@ -78,7 +78,8 @@ int dt_conv2d_uses_zi(const dt_conv_desc* d);  /* 1: parity-class tiles of the t
 /* ---- Winograd F(2x2,3x3) form of the 3x3 stride-1 pad-1 layers (same ATen conv2d / convolution_backward(input)
  * calls as dt_conv2d; 2.25x fewer multiplies, results within ~1e-6 relative of the direct form instead of an exact fma
  * chain).  u = dt_winograd_weights(w_hwio): G g G^T in the order [16 positions][Cin/8][2][Cout][4], 16*Cin*Cout floats.
- * Supported when C0, C1 are multiples of 8, Cout and cout_split multiples of 64, mode0 in {0,1}, sources < 2 GiB.
+ * Supported when C0, C1 are multiples of 8 and C0 + C1 of 16, Cout and cout_split multiples of 64, mode0 in {0,1}, every
+ * operand below 2 GiB (dt_conv2d_winograd_supported; callers fall back to dt_conv2d otherwise).
  * stats rows: dt_conv2d_winograd_stat_rows (16x16-pixel tiles). */
 int dt_conv2d_winograd_supported(const dt_conv_desc* d);
 int dt_conv2d_winograd_stat_rows(const dt_conv_desc* d);
