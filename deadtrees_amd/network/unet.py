@@ -64,7 +64,7 @@ class UNetEngine:
         # BatchNorm-backward reduction of a block-output layer inside the fp32 gradient-JOIN epilogue: measured slower
         # than the separate pass (526 vs 530 tiles/s, same box: 48 extra loads per lane in the read-modify-write
         # epilogue); the bf16 path keeps it (its join epilogue is LDS-staged, +0.5 %).  Kernel support stays tested.
-        self.fuse_join_fp32 = False
+        self.fuse_join_fp32 = bool(os.environ.get("DT_FUSE_JOIN_FP32"))
         self._fuse_bn = not os.environ.get("DT_NO_BN_FUSE")   # A/B switch for the plain fused reductions
         # fp32 3x3 stride-1 layers (forward + data gradient) on the Winograd F(2x2,3x3) kernel where its shape conditions
         # hold (conv_wino.hip: 1.6-2.0x the direct kernel per layer); DT_FP32_WINOGRAD=0 keeps the exact-fma direct kernel
