@@ -337,7 +337,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     for (int p = 0; p < 16; ++p) asm volatile("" ::"v"(acc[p]));
     return;
 #endif
-    const int tile = tile_of_round(round);
+    // everything derived from the tile index is wave-uniform; say so, or hipcc wraps each of the 64 buffer stores in a
+    // waterfall loop (readfirstlane / compare / saveexec per store: the scalar-offset operand must be provably uniform)
+    const int tile = __builtin_amdgcn_readfirstlane(tile_of_round(round));
     const int nt = tile % a.n_tiles, sp = tile / a.n_tiles;
     const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / tiles_per_img;
     const int oy0 = 16 * ty, ox0 = 16 * tx, n0 = 64 * nt;
@@ -370,8 +372,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void*)(a.bnb.act ? a.bnb.act : outp), 0, a.obytes0, 0x00020000);
     // addressing: byte offset = [tile base + (row, column) of the output inside the wave's block: scalar, in the
     // buffer op's SGPR offset] + [the lane's own part: 1 VGPR]; a pixel outside the map gets WN_OOB in the VGPR part
-    const int ld4 = ld * 4, row4 = a.Win * ld4;
-    const int tile_base = ((b * a.Hin + oy0 + 8 * wave_m) * a.Win + ox0) * ld4;   // rows 8 wm .. 8 wm + 7 of the tile
+    const int ld4 = __builtin_amdgcn_readfirstlane(ld * 4), row4 = __builtin_amdgcn_readfirstlane(a.Win * ld * 4);
+    const int tile_base = __builtin_amdgcn_readfirstlane(((b * a.Hin + oy0 + 8 * wave_m) * a.Win + ox0) * ld * 4);   // rows 8 wm .. 8 wm + 7
     const unsigned lane_base = (unsigned)(8 * kh * ld4 + nn * 4);
     const int xlane = ox0 + 8 * kh, ybase = oy0 + 8 * wave_m;
 #pragma unroll

@@ -318,3 +318,45 @@ def test_resunet_architecture_surface_and_reference_import_names(tmp_path, monke
     m.teardown()
     assert (tmp_path / "train_stats.csv").read_text() == "filename,count\na.tif,2\nb.tif,1\n"
     assert (tmp_path / "val_stats.csv").read_text() == "filename,count\nc.tif,1\n"
+
+
+def test_winograd_layer_selection_and_weight_image_tables():
+    """host side of the Winograd path (no GPU): which layers get a forward / data-gradient weight image, the image
+    offsets, and the shape predicates of the C ABI (dt_conv2d_winograd_supported, dt_conv2d_wgrad_winograd_supported)"""
+    import ctypes as C
+    from deadtrees_amd import _lib, ops
+    from deadtrees_amd.network.unet import UNetHIP
+    lib = _lib.load()
+    eng = UNetHIP().engine
+    tab, n, blocks, total, offs = eng._wino_table(torch.device("cpu"), False)
+    tabd, nd, blocksd, totald, offsd = eng._wino_table(torch.device("cpu"), True)
+    convs = {c.key: c for c in eng.spec.convs}
+    # forward: every 3x3 stride-1 layer with Cin % 16 == 0 and Cout % 64 == 0 — the encoder blocks and decoder blocks 0-2
+    want = {k for k, c in convs.items() if c.k == 3 and c.stride == 1 and c is not eng.spec.head and c.cin % 16 == 0 and c.cout % 64 == 0}
+    assert set(offs) == want and n == len(want) == 35      # 29 encoder convs + 6 of decoder blocks 0-2
+    assert not any(k.startswith(("decoder.blocks.3", "decoder.blocks.4")) for k in offs)
+    # data gradient: Cin / Cout swap -> also the 32-channel output layers whose input has a multiple of 64 channels
+    wantd = {k for k, c in convs.items() if c.k == 3 and c.stride == 1 and c is not eng.spec.head and c.cout % 16 == 0 and c.cin % 64 == 0}
+    assert set(offsd) == wantd and len(wantd) >= n
+    # images are packed back to back, 16 * Cin * Cout floats each, 16-byte aligned
+    end = 0
+    for row in tab.tolist():
+        w_off, u_off, cin, cout, first = row
+        assert u_off == end and u_off % 4 == 0
+        end += 16 * cin * cout
+    assert end == total and blocks == sum(((r[3] + 63) // 64) * ((r[2] // 4 + 3) // 4) for r in tab.tolist())
+    # shape predicates
+    d = ops.conv_desc(32, 128, 128, 64, 0, 0, 64, 3, 1, 1)
+    assert lib.dt_conv2d_winograd_supported(C.byref(d)) == 1 and lib.dt_conv2d_wgrad_winograd_supported(C.byref(d)) == 1
+    assert lib.dt_conv2d_winograd_stat_rows(C.byref(d)) == 32 * 8 * 8
+    for bad in (ops.conv_desc(32, 128, 128, 64, 0, 0, 32, 3, 1, 1),        # Cout 32
+                ops.conv_desc(32, 128, 128, 24, 0, 0, 64, 3, 1, 1),        # Cin 24: odd number of 8-channel chunks
+                ops.conv_desc(32, 128, 128, 64, 0, 0, 64, 1, 1, 0),        # 1x1
+                ops.conv_desc(32, 128, 128, 64, 0, 2, 64, 3, 1, 1),        # zero-insertion (transposed) input
+                ops.conv_desc(64, 512, 512, 64, 0, 0, 64, 3, 1, 1)):       # 4 GiB operands
+        assert lib.dt_conv2d_winograd_supported(C.byref(bad)) == 0
+    s2 = ops.conv_desc(32, 128, 128, 64, 0, 0, 128, 3, 2, 1)
+    assert lib.dt_conv2d_winograd_supported(C.byref(s2)) == 0 and lib.dt_conv2d_wgrad_winograd_supported(C.byref(s2)) == 0
+    d32 = ops.conv_desc(32, 256, 256, 32, 0, 0, 128, 3, 1, 1)              # dec.3 data gradient: forward form only
+    assert lib.dt_conv2d_winograd_supported(C.byref(d32)) == 1 and lib.dt_conv2d_wgrad_winograd_supported(C.byref(d32)) == 0
+    assert lib.dt_conv2d_wgrad_winograd_workspace(C.byref(d)) > 0 and lib.dt_conv2d_wgrad_winograd_workspace(C.byref(d32)) == 0
