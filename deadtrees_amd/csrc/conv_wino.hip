@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   // (beyond num_records of the buffer descriptor -> the load returns 0) for padding and past the last tile.
   // One buffer_load_dwordx2 per pixel and chunk: no branches, no 64-bit address arithmetic.
   unsigned off0[16], off1[16];
+  unsigned long long l_rmask[4] = {0, 0, 0, 0}, l_cmask[4] = {0, 0, 0, 0};
   int l_round = 0, l_chunk = 0;
   auto setup_offsets = [&](int round) {
     const bool live = round < my_tiles;
@@ -123,6 +124,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
         off0[4 * i + j] = ok ? (unsigned)(p0 * a.C0 + 2 * q) * 4u : WN_OOB;
         off1[4 * i + j] = ok ? (unsigned)(p1 * a.C1 + 2 * q) * 4u : WN_OOB;
       }
+    if constexpr (TF) {   // validity of the patch rows / columns as lane masks (SGPR pairs): pixel (i,j) = row i & column j
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        l_rmask[i] = __builtin_amdgcn_ballot_w64(live && (unsigned)(iy + i) < (unsigned)a.Hin);
+        l_cmask[i] = __builtin_amdgcn_ballot_w64((unsigned)(ix + i) < (unsigned)a.Win);
+      }
+    }
   };
   auto advance_loads = [&]() {
     if (++l_chunk == nch) {
@@ -146,7 +154,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   };
   // the producer's BatchNorm-apply + ReLU on the real pixels of source 0 (zero padding stays zero: a padded pixel was
   // loaded as exactly 0 and is recognised by the validity bit taken when the set was loaded)
-  unsigned dval[2] = {0, 0};
+  // 5 VALU instructions per pixel pair (fp32 MFMA and VALU work compete on this part: every one of them costs matrix
+  // time): v_pk_fma_f32, two v_max_f32, two v_cndmask_b32 with the pixel's validity lane mask straight from SGPRs
+  // (row mask & column mask of the tile the set was loaded for: scalar ops).  The fused multiply-add differs from the
+  // mul + add of bn_act / the direct kernels by at most one rounding (6e-8 relative; the Winograd transform itself 1e-6).
+  unsigned long long drm[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, dcm[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   f32x2 tf_sc = {1.f, 1.f}, tf_sh = {0.f, 0.f}, tf_v[2];
   float tf_lo = 0.f;
   // branch-free: a chunk of source 1 (no transform) runs with scale 1, shift 0 and a ReLU floor of -inf
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   auto tf_a = [&](auto set_tag, int i) {
     if constexpr (TF) {
       constexpr int SET = decltype(set_tag)::value;
-      tf_v[i & 1] = d[SET][i] * tf_sc + tf_sh;
+      tf_v[i & 1] = __builtin_elementwise_fma(d[SET][i], tf_sc, tf_sh);
     }
   };
   auto tf_b = [&](auto set_tag, int i) {
@@ -178,18 +190,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
       f32x2 v = tf_v[i & 1];
       v[0] = __builtin_fmaxf(v[0], tf_lo);
       v[1] = __builtin_fmaxf(v[1], tf_lo);
-      const bool valid = ((dval[SET] >> i) & 1u) != 0;   // a padded pixel was loaded as exactly 0 and stays 0
-      d[SET][i][0] = valid ? v[0] : d[SET][i][0];
-      d[SET][i][1] = valid ? v[1] : d[SET][i][1];
+      const unsigned long long m = drm[SET][i >> 2] & dcm[SET][i & 3];   // a padded pixel was loaded as exactly 0 and stays 0
+      float o0, o1;
+      asm volatile("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %5, %6, %4"
+                   : "=&v"(o0), "=&v"(o1)
+                   : "v"(d[SET][i][0]), "v"(v[0]), "s"(m), "v"(d[SET][i][1]), "v"(v[1]));
+      d[SET][i][0] = o0;
+      d[SET][i][1] = o1;
     }
   };
   auto mark_valid = [&](auto set_tag) {
     if constexpr (TF) {
       constexpr int SET = decltype(set_tag)::value;
-      unsigned m = 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m |= (off0[i] != WN_OOB ? 1u : 0u) << i;
-      dval[SET] = m;
+      for (int i = 0; i < 4; ++i) {
+        drm[SET][i] = l_rmask[i];
+        dcm[SET][i] = l_cmask[i];
+      }
     }
   };
   // B^T d B in registers: column j of B^T d, then row i of (B^T d) B -> 4 positions of (tile wt, channels 2q, 2q+1)
