@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
   const int chunk0 = split * a.cps;
 
   f32x2 dx[2][16], dg[2][4], t[16];
-  unsigned xvalid[2] = {0, 0};
+  unsigned long long xrm[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, xcm[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // row / column validity lane masks
   // ---- load context: the tile this thread stages in the NEXT chunk to be loaded (runs two chunks ahead of the MFMAs).
   // Tile coordinates advance incrementally (8 tiles per chunk) — no divisions in the loop — and the 16 + 4 byte offsets
   // are row part + column part; an invalid row makes the row part WW_OOB (the sum stays beyond every buffer: sources
@@ -138,12 +138,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
     constexpr int SET = decltype(set_tag)::value;
     prep_cols();
     if constexpr (TF) {
-      unsigned m = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) m |= ((xrow[i] != WW_OOB && xcok[j]) ? 1u : 0u) << (4 * i + j);
-      xvalid[SET] = m;
+      for (int i = 0; i < 4; ++i) {
+        xrm[SET][i] = __builtin_amdgcn_ballot_w64(xrow[i] != WW_OOB);
+        xcm[SET][i] = __builtin_amdgcn_ballot_w64(xcok[i]);
+      }
     }
   };
   // the tile of the following chunk (after the chunk's loads are issued): 8 tiles further along the row; at the end of
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
   auto tf_a = [&](auto set_tag, int i) {
     if constexpr (TF) {
       constexpr int SET = decltype(set_tag)::value;
-      tf_v[i & 1] = dx[SET][i] * tf_sc + tf_sh;
+      tf_v[i & 1] = __builtin_elementwise_fma(dx[SET][i], tf_sc, tf_sh);   // like conv_wino.hip: 5 VALU per pixel pair
     }
   };
   auto tf_b = [&](auto set_tag, int i) {
@@ -195,9 +194,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
       f32x2 v = tf_v[i & 1];
       v[0] = __builtin_fmaxf(v[0], tf_lo);
       v[1] = __builtin_fmaxf(v[1], tf_lo);
-      const bool valid = ((xvalid[SET] >> i) & 1u) != 0;
-      dx[SET][i][0] = valid ? v[0] : dx[SET][i][0];
-      dx[SET][i][1] = valid ? v[1] : dx[SET][i][1];
+      const unsigned long long m = xrm[SET][i >> 2] & xcm[SET][i & 3];
+      float o0, o1;
+      asm volatile("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %5, %6, %4"
+                   : "=&v"(o0), "=&v"(o1)
+                   : "v"(dx[SET][i][0]), "v"(v[0]), "s"(m), "v"(dx[SET][i][1]), "v"(v[1]));
+      dx[SET][i][0] = o0;
+      dx[SET][i][1] = o1;
     }
   };
   // LDS image: [pos][k-half][k-step][64 channels]; tile tau is k-half tau >> 2, k-step tau & 3
