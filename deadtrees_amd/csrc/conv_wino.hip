@@ -50,6 +50,7 @@ struct WinoArgs {
   int B, Hin, Win, C0, C1, mode0;
   int Cout, cout_split, accumulate;
   int tiles_x, tiles_y, n_tiles, P, nchunks;
+  int pstats;                // 1: BatchNorm partial sums accumulated over the workgroup's tiles, ONE row per workgroup
   unsigned bytes0, bytes1;   // sizes of the two sources (buffer descriptors: out-of-range loads return 0)
   unsigned obytes0, obytes1; // sizes of the two outputs
   unsigned ubytes;           // size of the transformed weights
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   for (int p = 0; p < 16; ++p)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+  float ps1 = 0.f, ps2 = 0.f;
 
   const int aoff = kh * WN_PS + (32 * wm + r) * 4;
   const int boff = kh * WN_PS + (32 * wn + r) * 4;
@@ -465,7 +467,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     for (int p = 0; p < 16; ++p)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
-    if (a.stats != nullptr) {
+    if (a.stats != nullptr && a.pstats) {
+      ps1 += s1;
+      ps2 += s2;
+    } else if (a.stats != nullptr) {
       const float u1 = s1 + __shfl_xor(s1, 32, 64);
       const float u2 = s2 + __shfl_xor(s2, 32, 64);
       if (kh == 0) {
@@ -493,6 +498,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
       step(S1{});
     }
     epilogue(round);
+  }
+  // one row of BatchNorm partial sums per workgroup: every tile of this workgroup has the same channel block (host
+  // check: 32 % n_tiles == 0), so the sums stayed in registers; the other channel blocks of the row are written as zeros
+  // (the finalize pass then reads <= 256 rows: no separate row-reduction launch)
+  if (a.stats != nullptr && a.pstats) {
+    const int nt0 = tile_of_round(0) % a.n_tiles;
+    const float u1 = ps1 + __shfl_xor(ps1, 32, 64);
+    const float u2 = ps2 + __shfl_xor(ps2, 32, 64);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kh == 0) {
+      red[wm * 64 + 32 * wn + r] = u1;
+      red[128 + wm * 64 + 32 * wn + r] = u2;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      float* row = a.stats + ((size_t)which * a.P + blockIdx.x) * a.Cout;
+      for (int cb = 0; cb < a.n_tiles; ++cb)
+        row[64 * cb + c] = cb == nt0 ? red[which * 128 + c] + red[which * 128 + 64 + c] : 0.f;
+    }
   }
 }
 
@@ -586,8 +611,18 @@ extern "C" int dt_conv2d_winograd_supported(const dt_conv_desc* d) {
   return 1;
 }
 
+// rows of the partial-sum buffer: one per workgroup when every tile of a workgroup has the same channel block
+// (32 % n_tiles == 0 with the xcd-aware tile order), one per spatial tile otherwise
+static int wn_stat_rows(const dt_conv_desc* d, int* pstats) {
+  const int sp = d->B * dt_cdiv(d->Ho, 16) * dt_cdiv(d->Wo, 16), nt = d->Cout / 64;
+  const long total = (long)sp * nt;
+  *pstats = nt > 0 && (32 % nt) == 0;
+  return *pstats ? (int)(total < WN_MAX_WGS ? total : WN_MAX_WGS) : sp;
+}
+
 extern "C" int dt_conv2d_winograd_stat_rows(const dt_conv_desc* d) {
-  return d->B * dt_cdiv(d->Ho, 16) * dt_cdiv(d->Wo, 16);
+  int ps;
+  return wn_stat_rows(d, &ps);
 }
 
 int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* src1, const float* u, float* out0,
@@ -605,6 +640,7 @@ int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* s
   a.tiles_y = dt_cdiv(d->Ho, 16);
   a.n_tiles = d->Cout / 64;
   a.P = d->B * a.tiles_x * a.tiles_y;
+  const int sp_tiles = a.P;
   a.nchunks = (d->C0 + d->C1) / 8;
   const size_t px0 = (size_t)d->B * (d->mode0 ? (d->Hin / 2) * (size_t)(d->Win / 2) : (size_t)d->Hin * d->Win);
   const size_t b0 = px0 * d->C0 * 4, b1 = (size_t)d->B * d->Hin * d->Win * d->C1 * 4;
@@ -620,7 +656,8 @@ int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* s
   const bool bnb = a.bnb.y != nullptr, join = d->accumulate != 0;
   DT_REQUIRE(!bnb || stats != nullptr, "conv_winograd: fused BatchNorm-backward sums need the stats buffer");
   DT_REQUIRE(!(in_scale != nullptr && bnb), "conv_winograd: no input transform on the BatchNorm-backward form");
-  const int total = a.P * a.n_tiles;
+  const int total = sp_tiles * a.n_tiles;
+  a.P = wn_stat_rows(d, &a.pstats);       // rows of the statistics buffer (indexing stride of its two planes)
   dim3 g((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)), blk(256);   // persistent: one workgroup per CU
   if (in_scale != nullptr && join) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 2>), g, blk, 0, st, a, total);
   else if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 0>), g, blk, 0, st, a, total);

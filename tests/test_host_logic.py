@@ -348,7 +348,11 @@ def test_winograd_layer_selection_and_weight_image_tables():
     # shape predicates
     d = ops.conv_desc(32, 128, 128, 64, 0, 0, 64, 3, 1, 1)
     assert lib.dt_conv2d_winograd_supported(C.byref(d)) == 1 and lib.dt_conv2d_wgrad_winograd_supported(C.byref(d)) == 1
-    assert lib.dt_conv2d_winograd_stat_rows(C.byref(d)) == 32 * 8 * 8
+    assert lib.dt_conv2d_winograd_stat_rows(C.byref(d)) == 256          # one row per persistent workgroup (2048 tiles)
+    d192 = ops.conv_desc(2, 32, 32, 64, 0, 0, 192, 3, 1, 1)              # 3 channel blocks: one row per spatial tile
+    assert lib.dt_conv2d_winograd_stat_rows(C.byref(d192)) == 2 * 2 * 2
+    dsmall = ops.conv_desc(2, 32, 32, 64, 0, 0, 128, 3, 1, 1)            # 16 tiles on 16 workgroups
+    assert lib.dt_conv2d_winograd_stat_rows(C.byref(dsmall)) == 16
     for bad in (ops.conv_desc(32, 128, 128, 64, 0, 0, 32, 3, 1, 1),        # Cout 32
                 ops.conv_desc(32, 128, 128, 24, 0, 0, 64, 3, 1, 1),        # Cin 24: odd number of 8-channel chunks
                 ops.conv_desc(32, 128, 128, 64, 0, 0, 64, 1, 1, 0),        # 1x1
