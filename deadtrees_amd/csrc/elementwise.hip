@@ -225,6 +225,40 @@ extern "C" int dt_channel_sums(const float* g, float* workspace, int64_t n_pix, 
   return DT_OK;
 }
 
+// ------------------------------------------------------------------ channel-slice copies (dense decoders)
+// torch.cat of the Unet++ dense skip connections (smp UnetPlusPlusDecoder.forward; in-tree twin: reference
+// deadtrees/network/extra/efficientunetplusplus/decoder.py:170-177) and its backward: NHWC tensors, channel counts
+// multiples of 4.  wide[n, off : off + Cn] = narrow[n, :]   /   narrow[n, :] (+)= wide[n, off : off + Cn]
+__global__ __launch_bounds__(256) void channel_slice_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
+                                                            int64_t n4, int Cn4, int Cw4, int off4, int to_wide, int acc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t pix = i / Cn4;
+    const int c = (int)(i - pix * Cn4);
+    const int64_t w = pix * Cw4 + off4 + c;
+    if (to_wide) {
+      dst[w] = src[i];
+    } else {
+      f32x4 v = src[w];
+      if (acc) v += dst[i];
+      dst[i] = v;
+    }
+  }
+}
+
+extern "C" int dt_channel_slice(const float* src, float* dst, int64_t n_pix, int C_narrow, int C_wide, int offset,
+                                int to_wide, int accumulate, void* stream) {
+  DT_REQUIRE(src && dst && n_pix > 0 && C_narrow > 0 && C_wide >= C_narrow, "channel_slice: bad args");
+  DT_REQUIRE((C_narrow & 3) == 0 && (C_wide & 3) == 0 && (offset & 3) == 0 && offset >= 0 && offset + C_narrow <= C_wide,
+             "channel_slice: channel counts and offset must be multiples of 4 inside the wide tensor");
+  const int64_t n4 = n_pix * (C_narrow / 4);
+  const int grid = (int)(n4 / 256 + 1 < 8192 ? n4 / 256 + 1 : 8192);
+  hipLaunchKernelGGL(channel_slice_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst,
+                     n4, C_narrow / 4, C_wide / 4, offset / 4, to_wide, accumulate);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ BN apply (+residual) (+ReLU)
 __global__ __launch_bounds__(256) void bn_act_kernel(const f32x4* __restrict__ y, const float* __restrict__ scale,
                                                      const float* __restrict__ shift,

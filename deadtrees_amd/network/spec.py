@@ -56,13 +56,17 @@ class DecBlockSpec:
     in_ch: int = 0
     skip_ch: int = 0
     idc: Optional[ConvSpec] = None   # ResUnet: 1x1 identity_conv (with bias) of the block input, added to the output
+    name: str = ""                   # Unet++: node name x_{depth}_{layer}
+    low: str = ""                    # Unet++: the node / encoder feature that is upsampled into this block
+    cat: tuple = ()                  # Unet++: the nodes / encoder features concatenated as the skip, in order
 
 
 @dataclass
 class UNetSpec:
     in_channels: int
     classes: int
-    decoder_kind: str = "unet"     # "unet" (smp Unet decoder) or "resunet" (reference network/extra/resunet/decoder.py)
+    decoder_kind: str = "unet"     # "unet" (smp Unet decoder), "resunet" (reference network/extra/resunet/decoder.py) or
+                                   # "unetplusplus" (smp UnetPlusPlus: dense wiring of extra/efficientunetplusplus/decoder.py)
     stem: ConvSpec = None
     layers: List[List[BlockSpec]] = field(default_factory=list)
     decoder: List[DecBlockSpec] = field(default_factory=list)
@@ -75,8 +79,8 @@ class UNetSpec:
 
 
 def build_spec(in_channels: int = 3, classes: int = 2, decoder: str = "unet") -> UNetSpec:
-    if decoder not in ("unet", "resunet"):
-        raise ValueError(f"decoder {decoder!r}: 'unet' or 'resunet'")
+    if decoder not in ("unet", "resunet", "unetplusplus"):
+        raise ValueError(f"decoder {decoder!r}: 'unet', 'resunet' or 'unetplusplus'")
     s = UNetSpec(in_channels, classes, decoder)
     convs: List[ConvSpec] = []
 
@@ -103,6 +107,35 @@ def build_spec(in_channels: int = 3, classes: int = 2, decoder: str = "unet") ->
     enc = [512, 256, 128, 64, 64]
     in_ch = [enc[0]] + list(DECODER_CHANNELS[:-1])
     skip_ch = enc[1:] + [0]
+    if decoder == "unetplusplus":
+        # smp UnetPlusPlusDecoder: block x_{d}_{l} for l = 0..3, d = 0..l, plus x_0_4 (channel arithmetic and wiring as
+        # executed in reference network/extra/efficientunetplusplus/decoder.py:133-184, which copies it); blocks in
+        # FORWARD order, features f0..f4 = encoder outputs from the deepest (512 ch) to the stem (64 ch)
+        depth = len(in_ch) - 1
+        chans = {}
+        for l in range(depth):
+            for d in range(l + 1):
+                if d == 0:
+                    chans[(d, l)] = (in_ch[l], skip_ch[l] * (l + 1), DECODER_CHANNELS[l])
+                else:
+                    chans[(d, l)] = (skip_ch[l - 1], skip_ch[l] * (l + 1 - d), skip_ch[l])
+        chans[(0, depth)] = (in_ch[-1], 0, DECODER_CHANNELS[-1])
+        order = []
+        for li in range(depth):
+            for d in range(depth - li):
+                if li == 0:
+                    order.append(((d, d), f"f{d}", (f"f{d + 1}",)))
+                else:
+                    l = d + li
+                    order.append(((d, l), f"x_{d}_{l - 1}", tuple(f"x_{i}_{l}" for i in range(d + 1, l + 1)) + (f"f{l + 1}",)))
+        order.append(((0, depth), f"x_0_{depth - 1}", ()))
+        for (d, l), low, cat in order:
+            ic, sc, oc = chans[(d, l)]
+            p = f"decoder.blocks.x_{d}_{l}"
+            c1 = conv(f"{p}.conv1.0.weight", f"{p}.conv1.1", ic + sc, oc, 3, 1, 1)
+            c2 = conv(f"{p}.conv2.0.weight", f"{p}.conv2.1", oc, oc, 3, 1, 1)
+            s.decoder.append(DecBlockSpec(c1, c2, ic, sc, None, f"x_{d}_{l}", low, cat))
+        in_ch, skip_ch = [], []     # the plain decoder loop below adds nothing
     for i, (ic, sc, oc) in enumerate(zip(in_ch, skip_ch, DECODER_CHANNELS)):
         p = f"decoder.blocks.{i}"
         c1 = conv(f"{p}.conv1.0.weight", f"{p}.conv1.1", ic + sc, oc, 3, 1, 1)

@@ -155,6 +155,13 @@ int dt_bn_bwd_apply_frozen(const float* dout, const float* out_act, const float*
                            float* red, int P, float* dgamma, float* dbeta, float* dy, float* dres,
                            int dres_accumulate, int64_t n_pix, int C, void* stream);
 
+/* torch.cat of NHWC tensors along the channels and its backward (the dense skip connections of the Unet++ decoder:
+ * reference network/extra/efficientunetplusplus/decoder.py:170-177, same wiring as smp UnetPlusPlusDecoder).
+ * to_wide = 1: wide[n, offset : offset + C_narrow] = narrow[n, :] (src = narrow, dst = wide);
+ * to_wide = 0: narrow[n, :] (+)= wide[n, offset : offset + C_narrow] (src = wide, dst = narrow; += when accumulate). */
+int dt_channel_slice(const float* src, float* dst, int64_t n_pix, int C_narrow, int C_wide, int offset, int to_wide,
+                     int accumulate, void* stream);
+
 /* per-channel sums of g [n_pix][C] -> out[C]: the bias gradient of a biased convolution (ATen convolution_backward's
  * third output; here the 1x1 identity_conv of the ResUnet decoder).  workspace: dt_channel_sums_workspace floats. */
 int64_t dt_channel_sums_workspace(int64_t n_pix, int C);

@@ -143,3 +143,31 @@ def test_resunet_decoder_oracle_against_the_executed_reference(golden_dir):
     with torch.no_grad():
         got = plain(*[None if f is None else f.detach() for f in feats])
     np.testing.assert_allclose(got.numpy(), z["out_plain_eval"], rtol=1e-5, atol=1e-5)
+
+
+def test_unetplusplus_decoder_oracle_against_the_executed_reference_wiring(golden_dir):
+    """oracle/unetpp_ref.UnetPlusPlusDecoderRef against tests/golden/unetpp_decoder.npz: the reference's own dense decoder
+    class (network/extra/efficientunetplusplus/decoder.py — smp's UnetPlusPlusDecoder constructor and forward loop),
+    executed by oracle/make_golden_unetpp.py with smp's plain decoder block: same state_dict names (x_{depth}_{layer}),
+    output, every parameter and feature gradient, BatchNorm running statistics."""
+    import torch
+    from oracle.unetpp_ref import UnetPlusPlusDecoderRef
+    z = np.load(os.path.join(golden_dir, "unetpp_decoder.npz"))
+    enc_ch, dec_ch = tuple(int(v) for v in z["enc_ch"]), tuple(int(v) for v in z["dec_ch"])
+    dec = UnetPlusPlusDecoderRef(enc_ch, dec_ch)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")}
+    assert set(sd) == set(dec.state_dict()) and len(dec.blocks) == 11
+    dec.load_state_dict(sd)
+    dec.train()
+    feats = [None] + [torch.from_numpy(z[f"feat{i}"]).requires_grad_(True) for i in range(1, 6)]
+    out = dec(*feats)
+    np.testing.assert_allclose(out.detach().numpy(), z["out"], rtol=1e-5, atol=1e-5)
+    (out * torch.from_numpy(z["gout"])).sum().backward()
+    for i in range(1, 6):
+        np.testing.assert_allclose(feats[i].grad.numpy(), z[f"dfeat{i}"], rtol=1e-4, atol=1e-5)
+    for k, p in dec.named_parameters():
+        ref = z[f"grad:{k}"]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    for k, v in dec.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), z[f"after:{k}"], rtol=1e-5, atol=1e-6)
