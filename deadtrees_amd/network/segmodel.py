@@ -84,7 +84,7 @@ def create_combined_batch(batch: Dict[str, Any]):
     return img, mask, distmap, lu, stats
 
 
-_SUPPORTED_ELSEWHERE = ("unetplusplus", "unet++", "resunetplusplus", "resunet++",
+_SUPPORTED_ELSEWHERE = ("resunetplusplus", "resunet++",
                         "efficientunetplusplus", "efficientunet++")
 
 
@@ -99,6 +99,9 @@ class SemSegment(_Base):
         elif architecture == "resunet":     # the reference's in-tree ResUnet (segmodel.py:66-67): same encoder, residual
             def Model(**kw):                # decoder blocks + 1x1 head, on the same kernels
                 return UNetHIP(decoder="resunet", **kw)
+        elif architecture in ("unetplusplus", "unet++"):   # smp.UnetPlusPlus (segmodel.py:64-65): dense nested decoder
+            def Model(**kw):
+                return UNetHIP(decoder="unetplusplus", **kw)
         elif architecture in _SUPPORTED_ELSEWHERE:
             raise NotImplementedError(
                 f"architecture {architecture!r} exists in the reference but has no MI355X kernels in this build "

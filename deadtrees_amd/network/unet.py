@@ -318,10 +318,15 @@ class UNetEngine:
                 cur, ch, cw = out, h2, w2
             feats.append(cur)
         # feats = [f1, f2, f3, f4, f5]
-        d, dh, dw = feats[4], ch, cw
+        if sp.decoder_kind == "unetplusplus":
+            d, dh, dw = self._forward_unetpp(feats, params, bnstate, bnws, B, training, save, keep)
+            dec_blocks = []
+        else:
+            d, dh, dw = feats[4], ch, cw
+            dec_blocks = sp.decoder
         d_ss = None   # (scale, shift) when d is a raw conv output with a virtual activation
         skips = [feats[3], feats[2], feats[1], feats[0], None]
-        for i, blk in enumerate(sp.decoder):
+        for i, blk in enumerate(dec_blocks):
             skip = skips[i]
             Hin, Win = 2 * dh, 2 * dw
             if sp.decoder_kind == "resunet":
@@ -375,6 +380,43 @@ class UNetEngine:
             sv.d["training"] = bool(training)
             self.saved = sv
         return logits, (am64 if am64 is not None else am8)
+
+    # ------------------------------------------------------------------ Unet++ decoder (smp UnetPlusPlus)
+    def _cat_channels(self, tensors):
+        """torch.cat(dim=1) of NHWC activations through dt_channel_slice -> (wide tensor, [(channel offset, width)])"""
+        if len(tensors) == 1:
+            return tensors[0], [(0, tensors[0].shape[-1])]
+        B, H, W = tensors[0].shape[:3]
+        Cw = sum(t.shape[-1] for t in tensors)
+        wide = torch.empty((B, H, W, Cw), dtype=torch.float32, device=tensors[0].device)
+        parts, off = [], 0
+        for t in tensors:
+            Cn = t.shape[-1]
+            _lib.check(self.lib.dt_channel_slice(_p(t), _p(wide), B * H * W, Cn, Cw, off, 1, 0, _stream()), "dt_channel_slice")
+            parts.append((off, Cn))
+            off += Cn
+        return wide, parts
+
+    def _forward_unetpp(self, feats, params, bnstate, bnws, B, training, save, keep):
+        """dense decoder of smp.UnetPlusPlus (wiring: reference network/extra/efficientunetplusplus/decoder.py:156-184):
+        every node x_{d}_{l} = DecoderBlock(up x2 of its lower node, cat of the nodes / encoder feature on its level).
+        Node outputs are materialised activations (they feed several consumers); conv2 reads conv1's raw output with the
+        BatchNorm+ReLU fused into its staging like everywhere else."""
+        sp = self.spec
+        nodes = {f"f{k}": feats[4 - k] for k in range(5)}     # f0 = deepest encoder feature ... f4 = stem output
+        for blk in sp.decoder:
+            low = nodes[blk.low]
+            Hin, Win = 2 * low.shape[1], 2 * low.shape[2]
+            skip, parts = (None, []) if not blk.cat else self._cat_channels([nodes[n] for n in blk.cat])
+            y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, low, skip, 1, B, Hin, Win, training,
+                                            save_stats=save)
+            y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
+                                            in_ss=ss1, save_stats=save)
+            z2 = self._bn_act(y2, ss2)
+            keep("P" + blk.name, x=low, skip=skip, parts=parts, y1=y1, y2=y2, z2=z2, H=h1, W=w1)
+            nodes[blk.name] = z2
+        out = nodes[sp.decoder[-1].name]
+        return out, out.shape[1], out.shape[2]
 
     # ------------------------------------------------------------------ bf16 inference leg
     def _weight_table(self, device):
@@ -1050,6 +1092,63 @@ class UNetEngine:
             desc = self._desc(B, Hin, Win, c.cout, 0, 2, Hin, Win, c.cin, c.k, 1, pad, split, 1 if acc else 0)
         self._conv(desc, dy, None, wd, out0, out1, None, u=self._u(c, dgrad=True) if c.stride == 1 else None)
 
+    def _backward_unetpp(self, S, g_head, params, grads, bnws, B, skip_grads):
+        """reverse of _forward_unetpp: the blocks in reverse forward order (every consumer of a node comes before the
+        node); a node's gradient is the sum over its consumers — as the upsampled input of the block to its right
+        (dt_upsample2x_bwd, accumulating) and as a slice of the concatenated skip of the blocks further right
+        (dt_channel_slice, accumulating).  Fills skip_grads (gradients of f1..f4) and returns the gradient of f5."""
+        sp, lib, st = self.spec, self.lib, _stream()
+        G = {sp.decoder[-1].name: g_head}
+
+        def slot(name, shape, dev):
+            t = G.get(name)
+            if t is None:
+                t = G[name] = torch.empty(shape, dtype=torch.float32, device=dev)
+                return t, 0
+            return t, 1
+
+        for blk in reversed(sp.decoder):
+            d = S["P" + blk.name]
+            g = G.pop(blk.name)
+            dev = g.device
+            Hh, Ww = d["H"], d["W"]
+            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"])
+            del g
+            self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+            dz1 = torch.empty_like(d["y1"])
+            if self._fuse_bn:
+                red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, d["y1"], bnws)
+            else:
+                red1 = self._dgrad(blk.conv2, params, dy2, B, Hh, Ww, dz1)
+            del dy2
+            dy1 = self._bn_bwd(blk.conv1, params, grads, bnws, dz1, None, d["y1"], virtual_act=True, reduced=red1)
+            del dz1
+            self._wgrad(blk.conv1, grads, d["x"], d["skip"], 1, B, Hh, Ww, dy1)
+            cx = blk.in_ch
+            dup = torch.empty((B, Hh, Ww, cx), dtype=torch.float32, device=dev)
+            dskip = None
+            if d["skip"] is not None:
+                dskip = torch.empty_like(d["skip"])
+                self._dgrad(blk.conv1, params, dy1, B, Hh, Ww, dup, dskip, split=cx)
+            else:
+                self._dgrad(blk.conv1, params, dy1, B, Hh, Ww, dup)
+            del dy1
+            glow, acc = slot(blk.low, d["x"].shape, dev)
+            _lib.check(lib.dt_upsample2x_bwd(_p(dup), _p(glow), acc, B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd")
+            del dup
+            if dskip is not None:
+                Cw = dskip.shape[-1]
+                for name, (off, Cn) in zip(blk.cat, d["parts"]):
+                    if len(blk.cat) == 1 and name not in G:
+                        G[name] = dskip                      # the skip was the tensor itself: its gradient as is
+                        continue
+                    gm, acc = slot(name, (B, Hh, Ww, Cn), dev)
+                    _lib.check(lib.dt_channel_slice(_p(dskip), _p(gm), B * Hh * Ww, Cn, Cw, off, 0, acc, st), "dt_channel_slice")
+            S["P" + blk.name] = None
+        for k in range(1, 5):
+            skip_grads[4 - k] = G[f"f{k}"]      # f_k of the decoder = feats[4 - k]
+        return G["f0"]
+
     def _backward_resunet_block(self, blk, d, g, params, grads, bnws, B, Hh, Ww, skip_grads, skip_slot):
         """reverse of one ResUnet decoder block (forward: see the decoder loop): g = gradient of the block output
         [B,Hh,Ww,cout] -> returns the gradient of the block's low-resolution input; writes the skip gradient."""
@@ -1135,7 +1234,9 @@ class UNetEngine:
             gw = grads[hd.w_off:hd.w_off + hd.w_size].view(K, 9, hd.cin)
             gw[:, :4].zero_()
             gw[:, 5:].zero_()
-        for i in range(4, -1, -1):
+        if sp.decoder_kind == "unetplusplus":
+            g = self._backward_unetpp(S, g, params, grads, bnws, B, skip_grads)
+        for i in (range(4, -1, -1) if sp.decoder_kind != "unetplusplus" else ()):
             blk = sp.decoder[i]
             d = S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
@@ -1297,7 +1398,8 @@ class UNetHIP(nn.Module):
                  decoder_channels=(256, 128, 64, 32, 16), in_channels: int = 3, classes: int = 2,
                  decoder: str = "unet", decoder_use_batchnorm=True, decoder_attention_type=None, **unused):
         """decoder "unet": smp.Unet; "resunet": the reference's in-tree ResUnet (network/extra/resunet/model.py:57-103 —
-        residual decoder blocks with a 1x1 identity_conv, 1x1 segmentation head), fp32 path."""
+        residual decoder blocks with a 1x1 identity_conv, 1x1 segmentation head); "unetplusplus": smp.UnetPlusPlus (dense
+        nested decoder x_{depth}_{layer}, 3x3 head).  The two alternatives run on the fp32 path."""
         super().__init__()
         if decoder_use_batchnorm is not True or decoder_attention_type is not None:
             raise NotImplementedError("only decoder_use_batchnorm=True / decoder_attention_type=None have HIP kernels")

@@ -301,9 +301,20 @@ def test_resunet_architecture_surface_and_reference_import_names(tmp_path, monke
     m.model.load_state_dict(ref.state_dict())
     for k, v in ref.state_dict().items():
         assert torch.equal(m.model.state_dict()[k], v), k
-    for arch in ("unet++", "resunet++", "efficientunet++"):
+    for arch in ("resunet++", "efficientunet++"):
         with pytest.raises(NotImplementedError):
             SemSegment(default_network(architecture=arch), default_training())
+    # smp.UnetPlusPlus (reference segmodel.py:64-65): both spellings, smp key names, its parameter count
+    from oracle.unetpp_ref import make_unetpp_oracle
+    for arch in ("unet++", "UnetPlusPlus"):
+        mpp = SemSegment(default_network(architecture=arch), default_training())
+        assert mpp.model.spec.decoder_kind == "unetplusplus"
+    refpp = make_unetpp_oracle(3, 2, seed=1)
+    assert set(mpp.model.state_dict()) == set(refpp.state_dict())
+    assert sum(p.numel() for p in refpp.parameters()) == mpp.model.spec.n_true_params == 26_078_754
+    mpp.model.load_state_dict(refpp.state_dict())
+    for k, v in refpp.state_dict().items():
+        assert torch.equal(mpp.model.state_dict()[k], v), k
     for name in ("deadtrees.network.segmodel", "deadtrees.data.deadtreedata", "deadtrees.deployment.inference",
                  "deadtrees.deployment.tiler", "deadtrees.loss.losses", "deadtrees.loss.gdl", "deadtrees.loss.gwdl",
                  "deadtrees.utils.data_handling"):
