@@ -28,6 +28,9 @@ Pinning status:
     ``tests/golden/resunet_decoder.npz``; the resnet34 ENCODER stays unpinned.
   * ResUnet decoder (``resunet_ref.py``): pinned the same way (outputs, input gradients and
     parameter gradients of the reference's own ``ResUnetDecoder``).
+  * Unet++ decoder (``unetpp_ref.py``): dense wiring pinned by executing the reference's
+    ``extra/efficientunetplusplus/decoder.py`` (smp's UnetPlusPlusDecoder constructor / forward loop) with smp's plain
+    decoder block (``oracle/make_golden_unetpp.py`` -> ``tests/golden/unetpp_decoder.npz``).
   * bf16 training oracle (``unet_bf16_ref.py``): the fp32 restatement with bf16 roundings at
     the HIP path's storage points; ``dtype=float32`` reproduces the fp32 oracle exactly.
 """

@@ -64,7 +64,7 @@ def test_unetpp_forward_eval_parity_and_argmax(B, H, W, C, K):
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_unetpp_training_step_gradients(mode):
     """loss + every parameter gradient of one step against the fp64 oracle.  eval = frozen BatchNorm (the
-    well-conditioned case): each tensor within 2e-3 of its norm (a wiring error — a wrong member of a dense concat, a
+    well-conditioned case): each tensor within 1e-4 of its norm (measured 9.6e-6; a wiring error — a wrong member of a dense concat, a
     missing gradient contribution of one of a node's consumers — is O(0.1..1)); train = batch statistics: within 10x /
     5x (per tensor / overall) the fp32 CPU oracle's own distance from fp64, the yardstick of tests/test_model_gpu.py."""
     from deadtrees_amd.data.synthetic import synth_batch
@@ -96,7 +96,7 @@ def test_unetpp_training_step_gradients(mode):
         er = float((g32[k].double() - p.grad).norm())
         worst = max(worst, (eh / n, k))
         if mode == "eval":
-            assert eh <= 2e-3 * n, (k, eh / n, er / n)
+            assert eh <= 1e-4 * n, (k, eh / n, er / n)
         else:
             assert eh <= 10.0 * er + 1e-4 * n, (k, eh / n, er / n)
         tot_h += eh ** 2
