@@ -69,6 +69,11 @@ class UNetEngine:
         # fp32 3x3 stride-1 layers (forward + data gradient) on the Winograd F(2x2,3x3) kernel where its shape conditions
         # hold (conv_wino.hip: 1.6-2.0x the direct kernel per layer); DT_FP32_WINOGRAD=0 keeps the exact-fma direct kernel
         self.winograd = os.environ.get("DT_FP32_WINOGRAD", "1") != "0"
+        # conv1 activations of the blocks whose conv2 runs on the Winograd kernels are materialised (bn_act) instead of
+        # being applied while conv2 / its weight gradient stage their input: the fused form costs those kernels 11-13 %
+        # (every staging VALU instruction competes with the fp32 MFMAs), the extra pass 0.4 ms — measured 713 vs 704
+        # tiles/s; DT_MATERIALIZE_Z1=0 restores the fused form (a gain with the direct kernels: +2 % in round 1)
+        self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
         # when a dict: the bf16 training pass stores a copy of every intermediate tensor it produces under the
         # names of oracle/unet_bf16_ref.py (teacher-forced parity test); None in production
         self.trace: Optional[dict] = None
@@ -304,9 +309,11 @@ class UNetEngine:
                 xin = cur
                 y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw, training,
                                                         save_stats=save)
-                # z1 = relu(bn1(y1)) is virtual: conv2 applies it while staging y1
-                y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
-                                                in_ss=ss1, save_stats=save)
+                # z1 = relu(bn1(y1)) is virtual: conv2 applies it while staging y1 (A/B switch DT_MATERIALIZE_Z1:
+                # a stored activation instead, read by the plain convolution / weight-gradient kernels)
+                z1 = self._bn_act(y1, ss1) if self._mat_z1 else None
+                y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1 if z1 is None else z1, None, 0, B,
+                                                h1, w1, training, in_ss=ss1 if z1 is None else None, save_stats=save)
                 if blk.down is not None:
                     yd, _, _, ssd = self._conv_bn(blk.down, params, bnstate, bnws, xin, None, 0, B, ch, cw, training,
                                                   save_stats=save)
@@ -314,7 +321,7 @@ class UNetEngine:
                 else:
                     yd = None
                     out = self._bn_act(y2, ss2, res=xin)
-                keep(f"L{li}B{bi}", x=xin, y1=y1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
+                keep(f"L{li}B{bi}", x=xin, y1=y1, z1=z1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
                 cur, ch, cw = out, h2, w2
             feats.append(cur)
         # feats = [f1, f2, f3, f4, f5]
@@ -350,15 +357,16 @@ class UNetEngine:
                 continue
             y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training,
                                             in_ss=d_ss, save_stats=save)
-            y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, h1, w1, training,
-                                            in_ss=ss1, save_stats=save)
+            z1 = self._bn_act(y1, ss1) if (self._mat_z1 and blk.conv2.cout % 64 == 0) else None
+            y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1 if z1 is None else z1, None, 0, B, h1, w1,
+                                            training, in_ss=ss1 if z1 is None else None, save_stats=save)
             if i == len(sp.decoder) - 1:
                 z2 = self._bn_act(y2, ss2)      # the head kernel reads a materialised activation
                 nxt, nxt_ss = z2, None
             else:
                 z2 = None                        # virtual: the next block's conv1 applies bn2+relu while staging
                 nxt, nxt_ss = y2, ss2
-            keep(f"D{i}", x=d, x_virtual=d_ss is not None, skip=skip, y1=y1, y2=y2, z2=z2, H=h1, W=w1)
+            keep(f"D{i}", x=d, x_virtual=d_ss is not None, skip=skip, y1=y1, z1=z1, y2=y2, z2=z2, H=h1, W=w1)
             d, dh, dw, d_ss = nxt, h2, w2, nxt_ss
 
         # ---- head
@@ -1247,7 +1255,10 @@ class UNetEngine:
             # conv2 + BN + ReLU (activation stored only for the last block)
             dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"], virtual_act=d["z2"] is None,
                                reduced=g_red)
-            self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+            if d.get("z1") is not None:
+                self._wgrad(blk.conv2, grads, d["z1"], None, 0, B, Hh, Ww, dy2)
+            else:
+                self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty_like(d["y1"])
             if self._fuse_bn:
                 red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, d["y1"], bnws)
@@ -1315,7 +1326,10 @@ class UNetEngine:
                     dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, r["out"], r["y2"], dres=gd, reduced=g_red)
                     dyd = self._bn_bwd(blk.down, params, grads, bnws, gd, None, r["yd"])
                     del gd
-                self._wgrad(blk.conv2, grads, r["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+                if r.get("z1") is not None:
+                    self._wgrad(blk.conv2, grads, r["z1"], None, 0, B, Hh, Ww, dy2)
+                else:
+                    self._wgrad(blk.conv2, grads, r["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
                 dz1 = torch.empty_like(r["y1"])
                 if self._fuse_bn:
                     red1 = self._dgrad_bn(blk.conv2, dy2, B, Hh, Ww, dz1, blk.conv1, r["y1"], bnws)
