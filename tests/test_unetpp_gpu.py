@@ -66,7 +66,8 @@ def test_unetpp_training_step_gradients(mode):
     """loss + every parameter gradient of one step against the fp64 oracle.  eval = frozen BatchNorm (the
     well-conditioned case): each tensor within 1e-4 of its norm (measured 9.6e-6; a wiring error — a wrong member of a dense concat, a
     missing gradient contribution of one of a node's consumers — is O(0.1..1)); train = batch statistics: within 10x /
-    5x (per tensor / overall) the fp32 CPU oracle's own distance from fp64, the yardstick of tests/test_model_gpu.py."""
+    5x (per tensor / overall) the fp32 CPU oracle's own distance from fp64, the yardstick of tests/test_model_gpu.py, plus
+    2e-3 of the tensor's norm (single tensors where the CPU oracle happens to be exact to 1e-5 still see mask flips)."""
     from deadtrees_amd.data.synthetic import synth_batch
     from deadtrees_amd.loss.seg_loss import seg_loss
     from oracle.train_ref import loss_from_logits
@@ -98,7 +99,7 @@ def test_unetpp_training_step_gradients(mode):
         if mode == "eval":
             assert eh <= 1e-4 * n, (k, eh / n, er / n)
         else:
-            assert eh <= 10.0 * er + 1e-4 * n, (k, eh / n, er / n)
+            assert eh <= 10.0 * er + 2e-3 * n, (k, eh / n, er / n)     # a flipped ReLU mask moves a tensor by ~1e-3
         tot_h += eh ** 2
         tot_r += er ** 2
         tot += n ** 2
