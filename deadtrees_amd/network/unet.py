@@ -74,6 +74,8 @@ class UNetEngine:
         # (every staging VALU instruction competes with the fp32 MFMAs), the extra pass 0.4 ms — measured 713 vs 704
         # tiles/s; DT_MATERIALIZE_Z1=0 restores the fused form (a gain with the direct kernels: +2 % in round 1)
         self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
+        # the same for the decoder block outputs that feed a Winograd conv1 (716.6 vs 712.8 tiles/s)
+        self._mat_z2 = os.environ.get("DT_MATERIALIZE_Z2", "1" if self.winograd else "0") != "0"
         # when a dict: the bf16 training pass stores a copy of every intermediate tensor it produces under the
         # names of oracle/unet_bf16_ref.py (teacher-forced parity test); None in production
         self.trace: Optional[dict] = None
@@ -360,8 +362,8 @@ class UNetEngine:
             z1 = self._bn_act(y1, ss1) if (self._mat_z1 and blk.conv2.cout % 64 == 0) else None
             y2, h2, w2, ss2 = self._conv_bn(blk.conv2, params, bnstate, bnws, y1 if z1 is None else z1, None, 0, B, h1, w1,
                                             training, in_ss=ss1 if z1 is None else None, save_stats=save)
-            if i == len(sp.decoder) - 1:
-                z2 = self._bn_act(y2, ss2)      # the head kernel reads a materialised activation
+            if i == len(sp.decoder) - 1 or (self._mat_z2 and sp.decoder[i + 1].conv1.cout % 64 == 0):
+                z2 = self._bn_act(y2, ss2)      # the head kernel (or a Winograd conv1) reads a materialised activation
                 nxt, nxt_ss = z2, None
             else:
                 z2 = None                        # virtual: the next block's conv1 applies bn2+relu while staging
