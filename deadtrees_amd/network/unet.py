@@ -57,9 +57,14 @@ class UNetEngine:
         self.profile: Optional[list] = None
         self._weights_epoch = 0
         self._u_all = self._ud_all = None     # Winograd weight images of the current forward / backward pass
-        # side-stream weight gradients: measured SLOWER on MI355X (485 vs 528 tiles/s fp32, 1505 vs 1566 bf16): the
-        # co-resident wgrad / dgrad workgroups halve each other's occupancy and share the matrix pipe — off by default
-        self.overlap_wgrad = False
+        # Weight gradients on a side stream, concurrent with the data-gradient / BatchNorm chain.  Round 1 (direct
+        # kernels, 2 workgroups per CU): SLOWER (485 vs 528 tiles/s fp32, 1505 vs 1566 bf16) — co-resident wgrad / dgrad
+        # workgroups halve each other's occupancy and share the matrix pipe.  Round 2, fp32 Winograd path: the kernels
+        # own a whole CU (148 KB LDS, 512 registers per lane), nothing co-resides, and the second stream only fills
+        # the launch gaps and tails of the ~200 short kernels of the backward pass: 716.6 vs 701.6 tiles/s on one box.
+        # fp32: on with the Winograd kernels (DT_OVERLAP_WGRAD=0/1 overrides); bf16: off.
+        self.overlap_wgrad = os.environ.get("DT_OVERLAP_WGRAD", "1" if os.environ.get("DT_FP32_WINOGRAD", "1") != "0" else "0") != "0"
+        self.overlap_wgrad_bf16 = bool(os.environ.get("DT_OVERLAP_WGRAD_BF16"))
         self._bwd_training = True
         # BatchNorm-backward reduction of a block-output layer inside the fp32 gradient-JOIN epilogue: measured slower
         # than the separate pass (526 vs 530 tiles/s, same box: 48 extra loads per lane in the read-modify-write
@@ -802,7 +807,7 @@ class UNetEngine:
             return dy
 
         def wgrad(c, src0, src1, mode0, Hin, Win, dy, in_ss=None, side=True):
-            if side and self.overlap_wgrad:
+            if side and self.overlap_wgrad_bf16:
                 self._on_side(lambda: wgrad(c, src0, src1, mode0, Hin, Win, dy, in_ss, side=False), src0, src1, dy)
                 return
             Ho, Wo = dy.shape[1], dy.shape[2]
