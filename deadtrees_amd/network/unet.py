@@ -56,6 +56,8 @@ class UNetEngine:
         # when a list: every dt_conv2d launch appends (kernel name, algorithmic FLOPs, start, end events)
         self.profile: Optional[list] = None
         self._weights_epoch = 0
+        self._bn_epoch = 0            # bumped by every training-mode forward (running statistics written on the device)
+        self._affine_fresh = False
         self._u_all = self._ud_all = None     # Winograd weight images of the current forward / backward pass
         # Weight gradients on a side stream, concurrent with the data-gradient / BatchNorm chain.  Round 1 (direct
         # kernels, 2 workgroups per CU): SLOWER (485 vs 528 tiles/s fp32, 1505 vs 1566 bf16) — co-resident wgrad / dgrad
@@ -245,8 +247,9 @@ class UNetEngine:
                                                _p(scale), _p(shift), _stream()), "dt_bn_finalize")
         else:
             self._conv(desc, src0, src1, w, y, None, None, in_ss, u=u)
-            _lib.check(self.lib.dt_bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), BN_EPS, c.cout,
-                                                  _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
+            if not self._affine_fresh:   # inference: the coefficients of the previous call are still valid (see forward)
+                _lib.check(self.lib.dt_bn_eval_affine(_p(gamma), _p(beta), _p(rmean), _p(rvar), BN_EPS, c.cout,
+                                                      _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
             if save_stats:   # a backward pass may follow (frozen-BatchNorm fine-tuning): xhat uses the running stats
                 _lib.check(self.lib.dt_bn_eval_stats(_p(rmean), _p(rvar), BN_EPS, c.cout, _p(mean), _p(invstd),
                                                      _stream()), "dt_bn_eval_stats")
@@ -287,6 +290,14 @@ class UNetEngine:
         sv = _Saved() if save else None
         self._u_all = self._wino_fwd_weights(params)
         bnws = self._buf("bnws", 4 * sp.n_bn_channels, device=dev)
+        # repeated inference calls (tiled prediction): the 46 eval-mode scale/shift launches are skipped while neither the
+        # parameters nor the running statistics changed (torch's version counters + the epochs of the raw device writes)
+        if training:
+            self._bn_epoch += 1
+        akey = None if (training or save) else (params.data_ptr(), params._version, self._weights_epoch, bnstate.data_ptr(),
+                                                bnstate._version, self._bn_epoch, bnws.data_ptr())
+        self._affine_fresh = akey is not None and self._ws.get("affine_key") == akey
+        self._ws["affine_key"] = akey
         if save:
             # mean/invstd are needed by backward: keep a private copy target per forward
             bnws = torch.empty(4 * sp.n_bn_channels, dtype=torch.float32, device=dev)
@@ -589,9 +600,15 @@ class UNetEngine:
         wbc = self._bf16_weights(params, chunked=True)
         bnws = self._buf("bnws", 4 * sp.n_bn_channels, device=dev)
         bf = torch.bfloat16
+        akey = (params.data_ptr(), params._version, self._weights_epoch, bnstate.data_ptr(), bnstate._version,
+                self._bn_epoch, bnws.data_ptr())
+        fresh = self._ws.get("affine_key") == akey      # same coefficients as the previous inference call: skip 46 launches
+        self._ws["affine_key"] = akey
 
         def affine(c):
             ss = self._ss(c, bnws)
+            if fresh:
+                return ss
             _lib.check(lib.dt_bn_eval_affine(_p(params[c.g_off:c.g_off + c.cout]), _p(params[c.b_off:c.b_off + c.cout]),
                                              _p(bnstate[2 * c.bn_off:2 * c.bn_off + c.cout]),
                                              _p(bnstate[2 * c.bn_off + c.cout:2 * c.bn_off + 2 * c.cout]), BN_EPS,
@@ -672,6 +689,7 @@ class UNetEngine:
         if H % 32 or W % 32 or Cin != sp.in_channels:
             raise RuntimeError(f"bad input {tuple(x_nchw.shape)}")
         dev, st, bf = x_nchw.device, _stream(), torch.bfloat16
+        self._bn_epoch += 1          # running statistics are rewritten on the device (invalidates cached eval affines)
         wb = self._bf16_weights(params)
         wbc = self._bf16_weights(params, chunked=True)
         sv = _Saved()

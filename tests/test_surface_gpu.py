@@ -305,3 +305,47 @@ def test_graphed_tile_predictor_equals_eager(precision):
         got = gp(u8).clone()
         assert torch.equal(got, want)
     assert len(gp._graphs) == 2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cached_eval_affine_is_invalidated_by_training_and_by_state_loads(precision):
+    """repeated inference calls skip the eval-mode BatchNorm scale/shift launches; a training step (running statistics
+    and weights rewritten on the device), a load_state_dict and an in-place torch write must each invalidate the cache"""
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.trainer import HipTrainer
+    m = UNetHIP()
+    m.reset_parameters(seed=3)
+    m = m.to(DEV)
+    m.precision = precision
+    img, mask = synth_batch(2, 64, 64, 3, 2, seed=4)
+    img, mask = img.to(DEV), mask.to(DEV)
+
+    def fresh_copy_logits():
+        m2 = UNetHIP()
+        m2.load_state_dict(m.state_dict())
+        m2 = m2.to(DEV).eval()
+        m2.precision = precision
+        with torch.no_grad():
+            return m2(img)
+
+    m.eval()
+    with torch.no_grad():
+        a = m(img)
+        b = m(img)                                   # served with cached coefficients
+    assert torch.equal(a, b) and torch.equal(a, fresh_copy_logits())
+    tr = HipTrainer(m, precision=precision)
+    tr.step(img, mask)
+    m.eval()
+    with torch.no_grad():
+        c = m(img)
+    assert not torch.equal(a, c) and torch.equal(c, fresh_copy_logits())
+    sd = {k: (v * 1.5 if k.endswith("running_var") else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        d = m(img)
+    assert not torch.equal(c, d) and torch.equal(d, fresh_copy_logits())
+    with torch.no_grad():
+        m.flat_params.mul_(1.01)
+        e = m(img)
+    assert not torch.equal(d, e) and torch.equal(e, fresh_copy_logits())
