@@ -162,7 +162,11 @@ def train_leg(args, ctx, precision, B, headline):
         tr.step(img, mask)
     sync()
     prof = []
-    model.engine.profile = None if use_graph else prof   # graph replays run no Python hooks: see below
+    # fp32 default: the weight gradients run on a second HIP stream (UNetEngine.overlap_wgrad), so kernel lifetimes
+    # overlap and a per-kernel duration is no longer that kernel's own time.  Like the graph-replay case the per-kernel
+    # events therefore come from two SERIAL eager steps after the timed region (same kernels, same shapes, one stream).
+    overlapped = bool(getattr(model.engine, "overlap_wgrad", False)) and precision == "fp32"
+    model.engine.profile = None if (use_graph or overlapped) else prof   # graph replays run no Python hooks: see below
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -176,15 +180,24 @@ def train_leg(args, ctx, precision, B, headline):
     if distributed:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt)
-    if use_graph:
-        # per-kernel events for the roofline block come from two EAGER steps after the timed region (same kernels,
-        # same shapes; the timed steps above were graph replays)
+    serial_step_s = None
+    if use_graph or overlapped:
+        # per-kernel events for the roofline block come from two EAGER, single-stream steps after the timed region (same
+        # kernels, same shapes; the timed steps above were graph replays / had the weight gradients on a second stream)
         tr.use_graph = False
+        model.engine.overlap_wgrad = False
+        tr.step(img, mask)
+        torch.cuda.synchronize()
         model.engine.profile = prof
+        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0.record()
         for _ in range(2):
             tr.step(img, mask)
+        p1.record()
         torch.cuda.synchronize()
+        serial_step_s = float(p0.elapsed_time(p1)) * 1e-3 / 2
         model.engine.profile = None
+        model.engine.overlap_wgrad = overlapped
     # PCIe-inclusive rate (never `value`): the batch arrives in pinned host memory every step (fp32 image + int64
     # mask, what the reference's loader hands to Lightning) on a copy stream, overlapped with the previous step
     pcie = None
@@ -217,8 +230,9 @@ def train_leg(args, ctx, precision, B, headline):
     ms_per_step = 1e3 * wall / args.steps
 
     # ---- roofline of the dominant conv kernel (rank 0's launches)
-    prof_steps = 2 if use_graph else args.steps
+    prof_steps = 2 if (use_graph or overlapped) else args.steps
     step_s = float(e0.elapsed_time(e1)) * 1e-3 / args.steps
+    share_s = serial_step_s if (overlapped and serial_step_s) else step_s   # the step the profiled launches belong to
     agg = {}
     for name, flops, a, b, nbytes in prof:
         t = a.elapsed_time(b) * 1e-3
@@ -238,7 +252,12 @@ def train_leg(args, ctx, precision, B, headline):
                 "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
                 "algorithmic_bytes_per_launch": round(nb / n), "algorithmic_flops_per_launch": round(fl / n),
                 "hbm_GBps_algorithmic": round(nb / t / 1e9, 1),
-                "share_of_step": round((t / prof_steps) / step_s, 4)}
+                "share_of_step": round((t / prof_steps) / share_s, 4)}
+        if overlapped:
+            roof["measured_on"] = ("2 serial eager steps after the timed region (weight gradients on the main stream, "
+                                   f"{1e3 * serial_step_s:.2f} ms per step): the timed steps run them on a second stream, "
+                                   "which overlaps kernel lifetimes; profiles/r02_bench_b32_serial_kernel_stats.csv is "
+                                   "rocprofv3 of this command with DT_OVERLAP_WGRAD=0")
         if "wino" in name:
             # Winograd F(2x2,3x3): `achieved` keeps the contract's definition (ALGORITHMIC = direct-convolution FLOPs /
             # duration), so it can exceed the matrix peak; the kernel ISSUES 16/36 of them on the matrix cores
@@ -270,7 +289,7 @@ def train_leg(args, ctx, precision, B, headline):
         "whole_net": {"tflops": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12, 2),
                       "mfma_frac": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12 / peak_tf, 4),
                       "hbm_frac_step": round(per_gpu_tiles_s * bytes_per_tile / 1e9 / PEAK_HBM_GBS, 4),
-                      "conv_fwd_dgrad_share_of_step": round((conv_time / prof_steps) / step_s, 4)},
+                      "conv_fwd_dgrad_share_of_step": round((conv_time / prof_steps) / share_s, 4)},
         "roofline": roof,
     }
     # free this leg's buffers (saved activations, graph pool) before the next leg allocates its own

@@ -83,6 +83,7 @@ class UNetEngine:
         self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
         # the same for the decoder block outputs that feed a Winograd conv1 (716.6 vs 712.8 tiles/s)
         self._mat_z2 = os.environ.get("DT_MATERIALIZE_Z2", "1" if self.winograd else "0") != "0"
+        self._mat_z1_bf16 = bool(os.environ.get("DT_BF16_MAT_Z1"))
         # when a dict: the bf16 training pass stores a copy of every intermediate tensor it produces under the
         # names of oracle/unet_bf16_ref.py (teacher-forced parity test); None in production
         self.trace: Optional[dict] = None
@@ -754,14 +755,15 @@ class UNetEngine:
             for bi, blk in enumerate(blocks):
                 xin = cur
                 y1, h1, w1, ss1 = conv(blk.conv1, xin, None, 0, ch, cw)
-                y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+                z1 = bn_act(y1, ss1) if self._mat_z1_bf16 else None      # A/B switch DT_BF16_MAT_Z1 (see __init__)
+                y2, h2, w2, ss2 = conv(blk.conv2, y1 if z1 is None else z1, None, 0, h1, w1, in_ss=ss1 if z1 is None else None)
                 if blk.down is not None:
                     yd, _, _, ssd = conv(blk.down, xin, None, 0, ch, cw)
                     out = bn_act(y2, ss2, res=yd, res_ss=ssd)
                 else:
                     yd = None
                     out = bn_act(y2, ss2, res=xin)
-                sv.d[f"L{li}B{bi}"] = dict(x=xin, y1=y1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
+                sv.d[f"L{li}B{bi}"] = dict(x=xin, y1=y1, z1=z1, y2=y2, yd=yd, out=out, Hin=ch, Win=cw, H=h2, W=w2)
                 cur, ch, cw = out, h2, w2
             feats.append(cur)
         d, dh, dw, d_ss = feats[4], ch, cw, None
@@ -953,7 +955,10 @@ class UNetEngine:
                     self._tr(f"L{li}B{bi}.dyd", dyd)
                     del gd
                 self._tr(f"L{li}B{bi}.dy2", dy2)
-                wgrad(blk.conv2, r["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+                if r.get("z1") is not None:
+                    wgrad(blk.conv2, r["z1"], None, 0, Hh, Ww, dy2)
+                else:
+                    wgrad(blk.conv2, r["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
                 dz1 = torch.empty(r["y1"].shape, dtype=bf, device=dev)
                 red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, r["y1"])
                 del dy2
