@@ -83,7 +83,9 @@ class UNetEngine:
         self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
         # the same for the decoder block outputs that feed a Winograd conv1 (716.6 vs 712.8 tiles/s)
         self._mat_z2 = os.environ.get("DT_MATERIALIZE_Z2", "1" if self.winograd else "0") != "0"
-        self._mat_z1_bf16 = bool(os.environ.get("DT_BF16_MAT_Z1"))
+        # bf16: the input-transforming form of the LDS-DMA kernel stages its input through registers (no DMA); a stored
+        # bf16 activation (2 + 2 B per element) lets conv2 and its weight gradient run the pure-DMA form: 2,235 vs 2,203
+        self._mat_z1_bf16 = os.environ.get("DT_BF16_MAT_Z1", "1") != "0"
         # when a dict: the bf16 training pass stores a copy of every intermediate tensor it produces under the
         # names of oracle/unet_bf16_ref.py (teacher-forced parity test); None in production
         self.trace: Optional[dict] = None
@@ -770,14 +772,15 @@ class UNetEngine:
         skips = [feats[3], feats[2], feats[1], feats[0], None]
         for i, blk in enumerate(sp.decoder):
             y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw, in_ss=d_ss)
-            y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+            z1 = None      # materialising here too was measured neutral (2,236 vs 2,234): the decoder keeps the fused form
+            y2, h2, w2, ss2 = conv(blk.conv2, y1 if z1 is None else z1, None, 0, h1, w1, in_ss=ss1 if z1 is None else None)
             if i == len(sp.decoder) - 1:
                 z2 = bn_act(y2, ss2)
                 nxt, nxt_ss = z2, None
             else:
                 z2 = None
                 nxt, nxt_ss = y2, ss2
-            sv.d[f"D{i}"] = dict(x=d, x_virtual=d_ss is not None, skip=skips[i], y1=y1, y2=y2, z2=z2, H=h1, W=w1)
+            sv.d[f"D{i}"] = dict(x=d, x_virtual=d_ss is not None, skip=skips[i], y1=y1, z1=z1, y2=y2, z2=z2, H=h1, W=w1)
             d, dh, dw, d_ss = nxt, h2, w2, nxt_ss
         hd = sp.head
         K = hd.cout
@@ -888,7 +891,10 @@ class UNetEngine:
             Hh, Ww = d["H"], d["W"]
             dy2 = bn_bwd(blk.conv2, g, d["z2"], d["y2"], virtual_act=d["z2"] is None, reduced=g_red)
             self._tr(f"D{i}.dy2", dy2)
-            wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+            if d.get("z1") is not None:
+                wgrad(blk.conv2, d["z1"], None, 0, Hh, Ww, dy2)
+            else:
+                wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty(d["y1"].shape, dtype=bf, device=dev)
             red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, d["y1"])
             del dy2
