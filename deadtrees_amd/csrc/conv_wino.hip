@@ -7,20 +7,26 @@
 //   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A      per 4x4 input tile d -> 2x2 output tile Y  (Lavin & Gray 2016)
 //
 // Design (MI355X-first):
-//   * one workgroup (4 waves, one per SIMD, 512 registers each) owns 16x16 output pixels = 64 Winograd tiles x 64
-//     output channels; a wave owns 32 tiles x 32 channels and keeps all 16 transform-domain positions of them in
-//     256 accumulator registers (16 independent 32x32 MFMA tiles -> no dependent-issue stalls);
+//   * persistent workgroups, one per CU (4 waves, one per SIMD, 512 registers each; 148 KB of LDS); a tile = 16x16
+//     output pixels = 64 Winograd tiles x 64 output channels; a wave owns 32 tiles x 32 channels and keeps all 16
+//     transform-domain positions of them in 256 accumulator registers (16 independent 32x32 MFMA tiles);
 //   * the 16 element-wise products are 16 GEMMs over input channels on v_mfma_f32_32x32x2_f32;
-//   * per 8-channel chunk: every thread loads the 4x4 patch of one tile for 2 channels straight from global memory
-//     (upsample / concat / zero padding / the producer's BatchNorm+ReLU are index arithmetic and two VALU ops here),
-//     transforms it in registers (32 adds per channel) and writes the 16 positions to LDS `[pos][k-half][tile][4]`,
-//     so a wave's A operand of one position for the WHOLE chunk is one conflict-free ds_read_b128;
-//   * the transformed weights U = G g G^T are produced once per step by dt_winograd_weights in exactly the LDS image
-//     order `[pos][chunk][k-half][Cout][4]` and go global -> LDS by DMA (global_load_lds_dwordx4, no registers);
-//   * both LDS images are double-buffered: one barrier per chunk; the loads + transform of chunk c+1 are issued
-//     between the MFMA groups of chunk c;
-//   * output transform (24 adds per tile and channel) is lane-local on the accumulators; epilogue = 128-B row stores
-//     + per-channel sum / sum-of-squares partials for the following BatchNorm, like conv_fwd.hip.
+//   * per 8-channel chunk: every thread loads the 4x4 patch of one tile for 2 channels with 16 buffer loads (padding =
+//     an out-of-range offset -> 0: no branches; upsample / concat are index arithmetic, the producer's BatchNorm+ReLU 5
+//     VALU ops per pixel pair), transforms it in registers (32 packed adds) and writes the 16 positions to LDS
+//     `[pos][k-half][tile][4]`, so a wave's A operand of one position for the WHOLE chunk is one conflict-free
+//     ds_read_b128;
+//   * the transformed weights U = G g G^T are produced once per step for all layers (dt_winograd_weight_images) in
+//     exactly the LDS image order `[pos][chunk][k-half][Cout][4]` and go global -> LDS by DMA (buffer_load ... lds);
+//   * both LDS images are double-buffered: one barrier per chunk; everything but the MFMAs is issued in fixed slots
+//     between the 64 MFMAs of a chunk: weight DMAs of chunk c+1, patch loads of chunk c+2 (two register sets, across
+//     tile boundaries), BatchNorm / transform / LDS writes of chunk c+1;
+//   * output transform (24 adds per tile and channel) is lane-local on the accumulators; epilogue = buffer stores with
+//     scalar offsets (128-B rows) + per-channel sum / sum-of-squares (or BatchNorm-backward) partials, kept in
+//     registers over the workgroup's tiles where every tile of a workgroup has the same channel block.
+// Measured (B=32, scripts/bench_wino.py, TF/s of direct-convolution FLOPs, vs conv_fwd.hip): 64->64@128^2 167 vs 103,
+// 128->128@64^2 190 vs 110, 256->256@32^2 204 vs 114, 512->512@16^2 209 vs 110, 768->256@32^2 240 vs 127; matrix-pipe
+// utilisation 57 % (PMC) on 16/36 of the multiplies.  What limits it and what was tried: DESIGN.md section 5.
 #include "common.h"
 #include "conv_wino.h"
 
