@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   };
   // the producer's BatchNorm-apply + ReLU on the real pixels of source 0 (zero padding stays zero: a padded pixel was
   // loaded as exactly 0 and is recognised by the validity bit taken when the set was loaded)
-  // 5 VALU instructions per pixel pair (fp32 MFMA and VALU work compete on this part: every one of them costs matrix
-  // time): v_pk_fma_f32, two v_max_f32, two v_cndmask_b32 with the pixel's validity lane mask straight from SGPRs
+  // 5 VALU instructions per pixel pair (with one wave per SIMD the staging instructions are not free behind the MFMAs:
+  // halving them from 10 was worth 2-3 % of the kernel): v_pk_fma_f32, two v_max_f32, two v_cndmask_b32 with the pixel's validity lane mask straight from SGPRs
   // (row mask & column mask of the tile the set was loaded for: scalar ops).  The fused multiply-add differs from the
   // mul + add of bn_act / the direct kernels by at most one rounding (6e-8 relative; the Winograd transform itself 1e-6).
   unsigned long long drm[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, dcm[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};

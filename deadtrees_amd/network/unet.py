@@ -78,7 +78,7 @@ class UNetEngine:
         self.winograd = os.environ.get("DT_FP32_WINOGRAD", "1") != "0"
         # conv1 activations of the blocks whose conv2 runs on the Winograd kernels are materialised (bn_act) instead of
         # being applied while conv2 / its weight gradient stage their input: the fused form costs those kernels 11-13 %
-        # (every staging VALU instruction competes with the fp32 MFMAs), the extra pass 0.4 ms — measured 713 vs 704
+        # (one wave per SIMD: the staging instructions are not free behind the MFMAs), the extra pass 0.4 ms — measured 713 vs 704
         # tiles/s; DT_MATERIALIZE_Z1=0 restores the fused form (a gain with the direct kernels: +2 % in round 1)
         self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
         # the same for the decoder block outputs that feed a Winograd conv1 (716.6 vs 712.8 tiles/s)
