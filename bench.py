@@ -97,6 +97,22 @@ def main():
                                                             "hip_graph", "whole_net", "roofline")}}
         except Exception as e:  # noqa: BLE001
             out["legs"] = {"bf16_b64": {"error": f"{type(e).__name__}: {e}"}}
+    # SURVEY 8d's secondary metric in the same line: forward-only tiles/s and km^2/h of the tiled inference path
+    # (BASELINE configs[4]: 256x256 sub-tiles at batch 64, uint8 in / uint8 class map out; tiler-inclusive figure too)
+    if args.precision == "fp32" and not args.no_legs and world == 1:
+        try:
+            import copy
+            from deadtrees_amd.network.unet import UNetHIP
+            ia = copy.copy(args)
+            ia.size, ia.batch, ia.steps, ia.warmup, ia.graph = 256, 64, 5, 2, "auto"
+            im = UNetHIP(in_channels=3, classes=2)
+            im.reset_parameters(seed=0)
+            leg = infer_bench(ia, im.to(dev), dev, world, rank, distributed, as_leg=True)
+            out.setdefault("legs", {})["infer_fp32_256"] = {k: leg[k] for k in ("metric", "value", "unit", "ms_per_step", "km2_per_hour",
+                                                                                  "tiler_inclusive", "config", "whole_net")}
+            del im
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("legs", {})["infer_fp32_256"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
@@ -300,7 +316,7 @@ def train_leg(args, ctx, precision, B, headline):
     return out
 
 
-def infer_bench(args, model, dev, world, rank, distributed):
+def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
     """forward-only leg of the tiled inference path: uint8 RGBN sub-tiles resident in HBM -> normalise (fused
     kernel) -> U-Net forward (eval BN) -> uint8 class map from the head kernel.  One step = one batch."""
     import torch
@@ -416,6 +432,8 @@ def infer_bench(args, model, dev, world, rank, distributed):
            "tiler_inclusive": tiler,
            "foreground_pixels": int(out.sum()), "hip_graph": use_graph,
            "pcie_inclusive_tiles_per_s_per_gpu": None if pcie is None else round(pcie, 1)}
+    if as_leg:
+        return res
     if rank == 0:
         print(json.dumps(res), flush=True)
     if distributed:
