@@ -415,7 +415,7 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
         tiler = {"ms_per_2048_ortho_tile": round(1e3 * per_ortho, 2),
                  "subtiles_per_s": round(world * (2048 // S) ** 2 / per_ortho, 1),
                  "km2_per_hour": round(world * km2_ortho / per_ortho * 3600.0, 1),
-                 "what": "split + uint8 H2D + normalise/forward/argmax + uint8 D2H + merge, pageable host arrays",
+                 "what": "uint8 raster H2D + block split + normalise/forward/argmax + block merge on the device + uint8 map D2H, pageable host arrays",
                  "foreground_fraction": round(float(merged.mean()), 4)}
     tiles_s = B * world * args.steps / wall
     km2_per_tile = (S * 0.20002 / 1000.0) ** 2          # pixel 0.20002 m (scripts/computestats_inference.py:57-59)

@@ -174,16 +174,26 @@ class Tiler:
 
 
 def infer_tile(inference, arr_chw_u8: np.ndarray, subtile: int = 256, batch_size: int = 64, rank: int = 0,
-               world: int = 1, device: str = "cuda", group=None, tile_shape: Optional[Tuple[int, int]] = None) -> np.ndarray:
+               world: int = 1, device: str = "cuda", group=None, tile_shape: Optional[Tuple[int, int]] = None,
+               on_device: Optional[bool] = None) -> np.ndarray:
     """whole-tile inference of scripts/inference.py:80-115 on the MI355X path: split -> (uint8 H2D, normalise on the
     device) -> forward + fused argmax -> uint8 D2H -> merge.  With world > 1 the sub-tile batches j = rank (mod world)
-    are processed locally and the uint8 class maps are all-gathered (no other collective: tiles are independent)."""
+    are processed locally and the uint8 class maps are all-gathered (no other collective: tiles are independent).
+    ``on_device`` (default: single rank + uint8 raster + HIP device) does the block split / merge on the GPU as well:
+    one H2D copy of the raster, one D2H copy of the merged map (``_infer_tile_on_device``; same result, tested)."""
     if tile_shape is None:
         h, w = arr_chw_u8.shape[1], arr_chw_u8.shape[2]
         if h <= 2048 and w <= 2048 and 2048 % subtile == 0:
             tile_shape = (2048, 2048)           # the reference's tile (tiler.py:63)
         else:
             tile_shape = (-(-h // subtile) * subtile, -(-w // subtile) * subtile)
+    if on_device is None:
+        on_device = (world == 1 and str(device).startswith("cuda") and torch.cuda.is_available()
+                     and arr_chw_u8.dtype == np.uint8)
+    if on_device:
+        if world != 1:
+            raise ValueError("infer_tile: the on-device split / merge is the single-rank form")
+        return _infer_tile_on_device(inference, arr_chw_u8, subtile, batch_size, device, tile_shape)
     t = Tiler(tile_shape=tile_shape, subtile_shape=(subtile, subtile))
     t.load_array(arr_chw_u8)
     used = t.get_batches()
@@ -203,3 +213,28 @@ def infer_tile(inference, arr_chw_u8: np.ndarray, subtile: int = 256, batch_size
                 outs[j] = o
     t.put_batches(np.concatenate(outs, axis=0))
     return t.result
+
+
+def _infer_tile_on_device(inference, arr_chw_u8: np.ndarray, subtile: int, batch_size: int, device: str,
+                          tile_shape: Tuple[int, int]) -> np.ndarray:
+    """single-rank form of ``infer_tile`` with the block split / merge on the device: ONE uint8 H2D copy of the raster, the
+    sub-tiles of ``Tiler.get_batches`` (same ones, same row-major order: the [0:ceil(h/d), 0:ceil(w/d)] blocks of the
+    zero-padded tile, reference tiler.py:121-134 + utils/data_handling.py:9-20) as a strided view -> NHWC uint8 batches
+    -> ``run_u8`` -> class maps merged like ``unmake_blocks_vectorized`` -> ONE uint8 D2H copy of the cropped map."""
+    C, h, w = arr_chw_u8.shape
+    d = subtile
+    if h > tile_shape[0] or w > tile_shape[1]:
+        raise ValueError(f"raster {(h, w)} larger than the tile shape {tuple(tile_shape)}")
+    if tile_shape[0] % d or tile_shape[1] % d:
+        raise ValueError(f"Shapes unaligned: {tuple(tile_shape)} / {d}")
+    nby, nbx = -(-h // d), -(-w // d)
+    x = torch.from_numpy(np.ascontiguousarray(arr_chw_u8)).to(device, non_blocking=True)
+    if (nby * d, nbx * d) != (h, w):
+        xp = torch.zeros((C, nby * d, nbx * d), dtype=torch.uint8, device=x.device)
+        xp[:, :h, :w] = x
+        x = xp
+    blocks = x.view(C, nby, d, nbx, d).permute(1, 3, 2, 4, 0).contiguous().view(nby * nbx, d, d, C)
+    outs = [inference.run_u8(blocks[j:j + batch_size], device=device) for j in range(0, nby * nbx, batch_size)]
+    maps = torch.cat(outs, dim=0).to(torch.uint8)
+    merged = maps.view(nby, nbx, d, d).permute(0, 2, 1, 3).reshape(nby * d, nbx * d)
+    return merged[:h, :w].contiguous().cpu().numpy()

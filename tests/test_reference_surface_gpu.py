@@ -88,6 +88,9 @@ def test_tiled_inference_at_configs4_size_uint8_path_equals_reference_style_path
     ragged = full[:, :1500, :2000]
     m2 = infer_tile(inf, ragged, subtile=256, batch_size=64, device=DEV)
     assert m2.shape == (1500, 2000)
+    # block split / merge on the device (default on one rank) == the host Tiler path (reference contract), bit for bit
+    np.testing.assert_array_equal(m2, infer_tile(inf, ragged, subtile=256, batch_size=64, device=DEV, on_device=False))
+    np.testing.assert_array_equal(merged, infer_tile(inf, full, subtile=256, batch_size=24, device=DEV, on_device=False))
     # sub-tiles fully inside the valid region see the same pixels in both runs
     np.testing.assert_array_equal(m2[:1280, :1792], merged[:1280, :1792])
     # the rank-sharded queue (world 2: batches j = rank mod 2, tests/test_dp_gloo.py runs it over gloo): the two
