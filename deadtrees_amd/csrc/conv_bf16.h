@@ -15,6 +15,7 @@ struct ConvBfArgs {
   // sum g, sum g*xhat of the layer this data gradient belongs to instead of sum v, sum v^2
   dt_bn_bwd_fuse bnb;
   int B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, pad, tiles_x, tiles_y, n_tiles, P, cout_split, accumulate;
+  int pstats = 0;   // conv_bf16_dma.hip: BatchNorm partial sums accumulated over a workgroup's tiles, one row per workgroup
 };
 
 // ---- LDS-DMA staged, double-buffered 3x3 stride-1 kernel (conv_bf16_dma.hip): 512-pixel x 64-channel tiles

@@ -1139,18 +1139,38 @@ extern "C" size_t dt_conv2d_wgrad_bf16_workspace(const dt_conv_desc* d) {
   int tw, ks, T, cib, cob;
   wb_cfg(d, &tw, &ks, &T, &cib, &cob);
   const size_t E = (size_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
-  const int rb = ks > 16 ? dt_cdiv(ks, 16) : 1;
-  const int parts2 = ks > 16 ? dt_cdiv(ks, rb) : 0;
-  return ((size_t)ks + parts2) * E * sizeof(float);
+  return (size_t)ks * E * sizeof(float);
 }
 
+// dw[e] = sum_p ws[p][e] in ONE launch whatever the number of split-K slabs: a workgroup owns 64 consecutive elements
+// (16 float4 quads) x 16 slab-lanes; every lane sums its slabs p = lane, lane + 16, ... in fp32 (4 independent
+// accumulators: memory-level parallelism), the 16 lanes are combined in fp64 in a fixed order -> deterministic
 __global__ __launch_bounds__(256) void wgrad_bf16_final_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                int parts, int64_t E) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
-    double s = 0.0;
-    for (int p = 0; p < parts; ++p) s += (double)ws[(size_t)p * E + e];
-    dw[e] = (float)s;
+  __shared__ f32x4 sh[256];
+  const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int64_t E4 = E >> 2, e4 = (int64_t)blockIdx.x * 16 + q;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  if (e4 < E4) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(ws) + e4;
+    int p = rl;
+    for (; p + 48 < parts; p += 64) {
+      const f32x4 v0 = src[(size_t)p * E4], v1 = src[(size_t)(p + 16) * E4];
+      const f32x4 v2 = src[(size_t)(p + 32) * E4], v3 = src[(size_t)(p + 48) * E4];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; p < parts; p += 16) a0 += src[(size_t)p * E4];
+  }
+  sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && e4 < E4) {
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 16; ++i) {
+      const f32x4 v = sh[i * 16 + q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] += (double)v[k];
+    }
+    reinterpret_cast<f32x4*>(dw)[e4] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
   }
 }
 
@@ -1204,19 +1224,9 @@ extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, con
   else rc = tw == 32 ? wb_launch<1, 2, 32>(a, grid, st) : wb_launch<1, 2, 16>(a, grid, st);
   if (rc != DT_OK) return rc;
   const int64_t E = (int64_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
-  const float* slabs = workspace;
-  int nslabs = a.ksplit;
-  if (a.ksplit > 16) {
-    const int rb = dt_cdiv(a.ksplit, 16);
-    float* stage = workspace + (size_t)a.ksplit * E;
-    rc = dt_reduce_rows_launch(workspace, stage, 1, a.ksplit, (int)E, rb, st);
-    if (rc != DT_OK) return rc;
-    slabs = stage;
-    nslabs = dt_cdiv(a.ksplit, rb);
-  }
-  int64_t g = (E + 255) / 256;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(wgrad_bf16_final_kernel, dim3((unsigned)g), dim3(256), 0, st, slabs, dw_hwio, nslabs, E);
+  DT_REQUIRE((E & 3) == 0, "wgrad_bf16: weight tensor size must be a multiple of 4");
+  const int64_t g = (E / 4 + 15) / 16;
+  hipLaunchKernelGGL(wgrad_bf16_final_kernel, dim3((unsigned)g), dim3(256), 0, st, workspace, dw_hwio, a.ksplit, E);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

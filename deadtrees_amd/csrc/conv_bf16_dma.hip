@@ -208,6 +208,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
     if constexpr (TF) stage_write(0);
   }
   int step = 0;
+  // BatchNorm (backward) partial sums: per tile, or — a.pstats: every tile of this workgroup has the same channel block —
+  // kept in registers over all of the workgroup's tiles and written as ONE row per workgroup after the loop (<= 256 rows:
+  // the finalize pass reads them directly, no row-reduction launch; no per-tile barriers / LDS passes for the sums)
+  float s1[NT], s2[NT], q1[8], q2[8];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q1[k] = q2[k] = 0.f;
+  const bool pstats = a.pstats != 0;
   for (int tile = blockIdx.x; tile < total_tiles; tile += G) {
     const int wg = (int)xcd_remap((unsigned)tile, (unsigned)total_tiles);
     const int nt = wg % a.n_tiles, sp = wg / a.n_tiles;
@@ -301,18 +310,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
     // The tile's two 256-pixel halves (waves 0-3 / 4-7) pass through it one after the other, all 512 threads storing.
     __bf16* st16 = reinterpret_cast<__bf16*>(lds + cur);
     float* st32 = reinterpret_cast<float*>(lds + cur);
-    float s1[NT], s2[NT];
+    if (!pstats) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+      for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    }
     const bool second = a.cout_split > 0 && n0 >= a.cout_split;
     const int ld_all = a.cout_split > 0 ? (second ? a.Cout - a.cout_split : a.cout_split) : a.Cout;
     __bf16* outp = second ? a.out1 : a.out;
     const int nn0 = second ? n0 - a.cout_split : n0;
     // a split data gradient joins only into its first output (host: EPI 2 <=> accumulate)
     const bool join = JOIN && !second;
-    float q1[8], q2[8], b_mu[8], b_is[8], b_sc[8], b_sh[8];
+    float b_mu[8], b_is[8], b_sc[8], b_sh[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) q1[k] = q2[k] = b_mu[k] = b_is[k] = b_sc[k] = b_sh[k] = 0.f;
+    for (int k = 0; k < 8; ++k) b_mu[k] = b_is[k] = b_sc[k] = b_sh[k] = 0.f;
+    if (!pstats) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q1[k] = q2[k] = 0.f;
+    }
     if (bnb) {
       auto ld8 = [&](const float* p, float (&v)[8]) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg), hi = *reinterpret_cast<const f32x4*>(p + n0 + 8 * sg + 4);
@@ -428,7 +442,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
         }
       }
     }
-    if (bnb) {
+    if (pstats) {
+      // sums stay in registers until the workgroup's last tile
+    } else if (bnb) {
       // per-thread sums over its pixels of 8 channels -> per-channel sums over the 64 threads of a channel segment
       __syncthreads();
       float* qs = reinterpret_cast<float*>(lds + cur);   // [2][8][512]
@@ -466,6 +482,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
       }
     }
     // the next step's barrier orders these LDS reads before the DMA that will overwrite this buffer
+  }
+  if (pstats && a.stats != nullptr && (bnb || !JOIN)) {
+    // one row per workgroup (same arithmetic as the per-tile forms above); the other channel blocks of the row are zeros
+    const int nt0 = (int)xcd_remap(blockIdx.x, (unsigned)total_tiles) % a.n_tiles;
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();   // every wave is done with the operand / staging images (no DMA is in flight after the last step)
+    if (bnb) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[k * 512 + tid] = q1[k];
+        red[(8 + k) * 512 + tid] = q2[k];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+        const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+        if (h == 0) {
+          red[wave * TN + 32 * j + r] = t1;
+          red[8 * TN + wave * TN + 32 * j + r] = t2;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * TN) {
+      const int which = tid / TN, c = tid % TN;
+      float sum;
+      if (bnb) {
+        const float* col = red + (which * 8 + (c & 7)) * 512 + (c >> 3);
+        sum = 0.f;
+        for (int i = 0; i < PER_IT; ++i) sum += col[i * SEGS];   // fixed order
+      } else {
+        const float* rr = red + which * 8 * TN + c;
+        sum = ((rr[0] + rr[TN]) + (rr[2 * TN] + rr[3 * TN])) + ((rr[4 * TN] + rr[5 * TN]) + (rr[6 * TN] + rr[7 * TN]));
+      }
+      float* row = a.stats + ((size_t)which * a.P + blockIdx.x) * a.Cout;
+      for (int cb = 0; cb < a.n_tiles; ++cb) row[TN * cb + c] = cb == nt0 ? sum : 0.f;
+    }
   }
 }
 
@@ -513,17 +567,27 @@ int dt_conv_bf16_dma_supported(const dt_conv_desc* d) {
   return wgs >= 256;
 }
 
+// rows of the partial-sum buffer: one per workgroup when every tile of a (persistent) workgroup has the same channel
+// block — tile ids id, id + 256, ... through xcd_remap: 32 % n_tiles == 0 — one per spatial tile otherwise
+static int dm_stat_rows(int B, int Ho, int Wo, int Cout, int* pstats) {
+  const int sp = B * dt_cdiv(Ho, DM_TH) * dt_cdiv(Wo, DM_TW), nt = Cout / DM_TN;
+  const long total = (long)sp * nt;
+  *pstats = nt > 0 && (32 % nt) == 0;
+  return *pstats ? (int)(total < DM_MAX_WGS ? total : DM_MAX_WGS) : sp;
+}
+
 int dt_conv_bf16_dma_stat_rows(const dt_conv_desc* d) {
-  return d->B * dt_cdiv(d->Ho, DM_TH) * dt_cdiv(d->Wo, DM_TW);
+  int ps;
+  return dm_stat_rows(d->B, d->Ho, d->Wo, d->Cout, &ps);
 }
 
 int dt_conv_bf16_dma_launch(ConvBfArgs a, hipStream_t st) {
   a.tiles_x = dt_cdiv(a.Wo, DM_TW);
   a.tiles_y = dt_cdiv(a.Ho, DM_TH);
   a.n_tiles = a.Cout / DM_TN;
-  a.P = a.B * a.tiles_x * a.tiles_y;
+  const int total = a.B * a.tiles_x * a.tiles_y * a.n_tiles;
+  a.P = dm_stat_rows(a.B, a.Ho, a.Wo, a.Cout, &a.pstats);   // rows (= indexing stride) of the statistics buffer
   // persistent workgroups: one per CU (157 KB of LDS each), every one walks tiles id, id + grid, ...
-  const int total = a.P * a.n_tiles;
   const int grid = total < DM_MAX_WGS ? total : DM_MAX_WGS;
   const bool bnb = a.bnb.y != nullptr, join = a.accumulate != 0;
   DT_REQUIRE(!bnb || a.stats != nullptr, "conv_bf16_dma: fused BatchNorm-backward sums need the stats buffer");

@@ -126,95 +126,153 @@ extern "C" int dt_head_fwd_bf16(const void* x_bf16, const float* w, const float*
 // ------------------------------------------------------------------ head backward
 // dx[b,y,x,c] = sum_{k,kh,kw} dl[b,k,y+1-kh,x+1-kw] * w[k][kh][kw][c]
 // dW[k][kh][kw][c] = sum_pix x[b,y+kh-1,x+kw-1,c] * dl[b,k,y,x] ; dbias[k] = sum dl
-extern "C" int dt_head_bwd_rows(int B, int H, int W) { return B * dt_cdiv(H, HEAD_TH) * dt_cdiv(W, HEAD_TW); }
+//
+// Both are tiny-K GEMMs over an 8x32-pixel tile held in LDS (x halo 10x34x16, dl halo K x 10x34) and run on
+// v_mfma_f32_16x16x4_f32 (exact fp32 fma chains; the VALU form of round 1 was issue-bound at 29 % of the HBM rate):
+//   dx^T [16 c x 16 pixels]    = w^T [16 c x 9K (k,tap)]      x dl_shifted [9K x 16 pixels]   (ceil(9K/4) MFMAs per 16 pixels;
+//        D: lane = pixel, 4 consecutive channels -> ONE 16-byte (fp32) / 8-byte (bf16) store per lane, 1 KiB per wave)
+//   dW   [9K (k,tap) x 16 c]   = dl_shifted^T [9K x pixels]   x x [pixels x 16 c]             (K loop = the 10 x 36 halo pixels,
+//        4 per MFMA, the waves take every 4th step; accumulators live across the HB_TPW tiles of a workgroup)
+// dbias falls out of the dW loop: the A operand of a centre-tap row is dl of the tile's own pixels.
+#define HB_HWP 36                         // halo columns 34 + 2 zero columns: 9 K-steps of 4 pixels per halo row
+#define HB_HH (HEAD_TH + 2)
+#define HB_NPIX (HB_HH * HB_HWP)          // 360
+#define HB_TPW 8                          // tiles per workgroup (one partial dW row per workgroup)
+
+static inline int head_bwd_tiles(int B, int H, int W) { return B * dt_cdiv(H, HEAD_TH) * dt_cdiv(W, HEAD_TW); }
+extern "C" int dt_head_bwd_rows(int B, int H, int W) { return dt_cdiv(head_bwd_tiles(B, H, W), HB_TPW); }
 
 template <int K, bool XB = false>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ dl, void* __restrict__ dx,
-                                                       float* __restrict__ red, int B, int H, int W) {
+                                                       float* __restrict__ red, int B, int H, int W, int total_tiles) {
   constexpr int C = HEAD_CIN;
-  constexpr int HH = HEAD_TH + 2, HW_ = HEAD_TW + 2;
-  constexpr int NW = K * 9 * C + K;
-  __shared__ float xt[HH * HW_][C + 1];
-  __shared__ float dlt[K][HH * HW_];
+  constexpr int NR = 9 * K;                 // real (k, tap) rows
+  constexpr int MT = (NR + 15) / 16;        // 16-row M tiles of the dW GEMM
+  constexpr int KS = (NR + 3) / 4;          // K steps of the dx GEMM
+  constexpr int NW = K * 9 * C + K, NWP = (NW + 3) & ~3;
+  static_assert(4 * MT * 64 * 5 <= HB_NPIX * C, "the cross-wave reduction image fits the x tile");
+  __shared__ __attribute__((aligned(16))) float xt[HB_NPIX * C];   // [halo pixel][16 channels]: 16 j + c -> 64 distinct banks
+  __shared__ float dlt[K * HB_NPIX];
   const int tiles_x = (W + HEAD_TW - 1) / HEAD_TW, tiles_y = (H + HEAD_TH - 1) / HEAD_TH;
-  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
-  const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
-  const int t = threadIdx.x;
-  for (int i = t; i < HH * HW_ * (C / 4); i += 256) {
-    const int q = i % (C / 4), pix = i / (C / 4);
-    const int hy = pix / HW_, hx = pix % HW_;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-      v = head_load4<XB>(x, (((size_t)b * H + iy) * W + ix) * C + 4 * q);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 15, j = lane >> 4;
+
+  // ---- per-lane constants.  dx: A = w^T (row c = m, k index kk = 4 s + j), B = dl at halo (py + 2 - kh, px + 2 - kw)
+  float wA[KS];
+  int boff[KS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) xt[pix][4 * q + k] = v[k];
+  for (int s = 0; s < KS; ++s) {
+    const int kk = 4 * s + j;
+    const bool ok = kk < NR;
+    const int k = ok ? kk / 9 : 0, tap = ok ? kk % 9 : 0;
+    wA[s] = ok ? w[kk * C + m] : 0.f;
+    boff[s] = k * HB_NPIX + (2 - tap / 3) * HB_HWP + (2 - tap % 3);
   }
-  for (int i = t; i < K * HH * HW_; i += 256) {
-    const int k = i / (HH * HW_), pix = i % (HH * HW_);
-    const int hy = pix / HW_, hx = pix % HW_;
-    const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-    float v = 0.f;
-    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = dl[(((size_t)b * K + k) * H + iy) * W + ix];
-    dlt[k][pix] = v;
+  // dW: A row (k, tap) = 16 mt + m at halo pixel (hy, hx): dl of output pixel (hy - kh, hx - kw) if that lies in the tile
+  int aoff[MT], akh[MT], akw[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int rg = 16 * mt + m;
+    const bool ok = rg < NR;
+    const int k = ok ? rg / 9 : 0, tap = ok ? rg % 9 : 0;
+    akh[mt] = ok ? tap / 3 : 1000;       // an invalid row never passes the range test
+    akw[mt] = tap % 3;
+    aoff[mt] = k * HB_NPIX + (1 - tap / 3) * HB_HWP + (1 - tap % 3);
+  }
+  f32x4 accw[MT];
+  float asum[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    accw[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asum[mt] = 0.f;
+  }
+
+  for (int ti = 0; ti < HB_TPW; ++ti) {
+    const int tile = blockIdx.x * HB_TPW + ti;
+    if (tile >= total_tiles) break;     // uniform
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
+    if (ti > 0) __syncthreads();        // the previous tile's reads are done
+    for (int i = t; i < HB_NPIX * (C / 4); i += 256) {
+      const int q = i & 3, pix = i >> 2;
+      const int hy = pix / HB_HWP, hx = pix - hy * HB_HWP;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (hx < HEAD_TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = head_load4<XB>(x, (((size_t)b * H + iy) * W + ix) * C + 4 * q);
+      *reinterpret_cast<f32x4*>(xt + pix * C + 4 * q) = v;
+    }
+    for (int i = t; i < K * HB_NPIX; i += 256) {
+      const int k = i / HB_NPIX, pix = i - k * HB_NPIX;
+      const int hy = pix / HB_HWP, hx = pix - hy * HB_HWP;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      float v = 0.f;
+      if (hx < HEAD_TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = dl[(((size_t)b * K + k) * H + iy) * W + ix];
+      dlt[i] = v;
+    }
+    __syncthreads();
+    // ---- dx: wave w owns tile rows 2w, 2w+1 = 4 groups of 16 pixels
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int py = 2 * wave + (g >> 1), px = (g & 1) * 16 + m;
+      const int base = py * HB_HWP + px;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[s], dlt[boff[s] + base], a, 0, 0, 0);
+      const int oy = oy0 + py, ox = ox0 + px;
+      if (oy < H && ox < W) {
+        const size_t o = (((size_t)b * H + oy) * W + ox) * C + 4 * j;
+        if constexpr (XB) {
+          hbf16x4 v = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+          *reinterpret_cast<hbf16x4*>(reinterpret_cast<__bf16*>(dx) + o) = v;
+        } else {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + o) = a;
+        }
+      }
+    }
+    // ---- dW / dbias: K steps s = wave, wave + 4, ... of the 90 (halo row hy = s / 9, columns 4 (s % 9) + j)
+    for (int s = wave; s < HB_HH * (HB_HWP / 4); s += 4) {
+      const int hy = s / (HB_HWP / 4), hx = 4 * (s - hy * (HB_HWP / 4)) + j;
+      const int hp = hy * HB_HWP + hx;
+      const float bv = xt[hp * C + m];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool ok = (unsigned)(hy - akh[mt]) < (unsigned)HEAD_TH && (unsigned)(hx - akw[mt]) < (unsigned)HEAD_TW;
+        const float av = dlt[ok ? aoff[mt] + hp : 0];
+        const float a = ok ? av : 0.f;
+        asum[mt] += a;
+        accw[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, accw[mt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- one partial row per workgroup: the four waves' accumulators combined in a fixed order
+  __syncthreads();
+  float* rl = xt;   // [4 waves][MT][64 lanes][5]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float* d = rl + ((wave * MT + mt) * 64 + lane) * 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = accw[mt][i];
+    d[4] = asum[mt];
   }
   __syncthreads();
-  const int py = t / HEAD_TW, px = t % HEAD_TW;
-  const int oy = oy0 + py, ox = ox0 + px;
-  const bool valid = oy < H && ox < W;
-  // ---- dx
-  {
-    float a[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) a[c] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        // contribution of output pixel (y+1-kh, x+1-kw) -> halo coords (py+2-kh, px+2-kw)
-        const int hp = (py + 2 - kh) * HW_ + (px + 2 - kw);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const float g = dlt[k][hp];
-#pragma unroll
-          for (int c = 0; c < C; ++c) a[c] = fmaf(g, w[(k * 9 + kh * 3 + kw) * C + c], a[c]);   // scalar loads
-        }
-      }
-    if (valid) {
-      const size_t o = (((size_t)b * H + oy) * W + ox) * C;
-#pragma unroll
-      for (int q = 0; q < C / 4; ++q) {
-        if constexpr (XB) {
-          hbf16x4 v = {(__bf16)a[4 * q], (__bf16)a[4 * q + 1], (__bf16)a[4 * q + 2], (__bf16)a[4 * q + 3]};
-          *reinterpret_cast<hbf16x4*>(reinterpret_cast<__bf16*>(dx) + o + 4 * q) = v;
-        } else {
-          f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dx) + o + 4 * q) = v;
-        }
-      }
-    }
-  }
-  // ---- dW / dbias partials: one thread per (k, tap, c) output walks the tile's 256 pixels in LDS
-  // (dl broadcast within a wave, x rows 17-dword pitch): no cross-lane reduction needed.
-  constexpr int NWP = (NW + 3) & ~3;   // row pitch of `red` (multiple of 4 for the vectorised row reduction)
+  float* row = red + (size_t)blockIdx.x * NWP;
   for (int o = t; o < NWP; o += 256) {
-    float accw = 0.f;
-    if (o < K * 9 * C) {
-      const int c = o % C, tap = (o / C) % 9, k = o / (9 * C);
-      const int kh = tap / 3, kw = tap % 3;
-      for (int py2 = 0; py2 < HEAD_TH; ++py2) {
-        const float* dlr = &dlt[k][(py2 + 1) * HW_ + 1];
-        const int xrow = (py2 + kh) * HW_ + kw;
-#pragma unroll 8
-        for (int px2 = 0; px2 < HEAD_TW; ++px2) accw = fmaf(dlr[px2], xt[xrow + px2][c], accw);
-      }
+    float v = 0.f;
+    if (o < NR * C) {
+      const int rg = o / C, c = o % C;          // D row rg = 16 mt + 4 jj + i lives in lane 16 jj + c, register i
+      const int mt = rg >> 4, r16 = rg & 15;
+      const int src = (mt * 64 + (r16 >> 2) * 16 + c) * 5 + (r16 & 3);
+      v = (rl[src] + rl[src + MT * 320]) + (rl[src + 2 * MT * 320] + rl[src + 3 * MT * 320]);
     } else if (o < NW) {
-      const int k = o - K * 9 * C;
-      for (int py2 = 0; py2 < HEAD_TH; ++py2)
-        for (int px2 = 0; px2 < HEAD_TW; ++px2) accw += dlt[k][(py2 + 1) * HW_ + px2 + 1];
+      const int rg = 9 * (o - NR * C) + 4;      // centre tap of class k
+      const int mt = rg >> 4, r16 = rg & 15;
+      for (int wv = 0; wv < 4; ++wv)
+        for (int jj = 0; jj < 4; ++jj) v += rl[((wv * MT + mt) * 64 + jj * 16 + r16) * 5 + 4];
     }
-    red[(size_t)blockIdx.x * NWP + o] = accw;
+    row[o] = v;
   }
 }
 
@@ -223,13 +281,13 @@ static int head_bwd_launch(const void* x, const float* w, const float* dl, void*
                            int Cin, int K, void* stream) {
   DT_REQUIRE(x && w && dl && dx && red && B > 0 && H > 0 && W > 0, "head_bwd: bad args");
   DT_REQUIRE(Cin == HEAD_CIN && K >= 1 && K <= HEAD_MAXK, "head_bwd: unsupported Cin/K");
-  const int grid = dt_head_bwd_rows(B, H, W);
+  const int total = head_bwd_tiles(B, H, W), grid = dt_head_bwd_rows(B, H, W);
   hipStream_t st = (hipStream_t)stream;
   switch (K) {
-    case 1: hipLaunchKernelGGL((head_bwd_kernel<1, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
-    case 2: hipLaunchKernelGGL((head_bwd_kernel<2, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
-    case 3: hipLaunchKernelGGL((head_bwd_kernel<3, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
-    default: hipLaunchKernelGGL((head_bwd_kernel<4, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W); break;
+    case 1: hipLaunchKernelGGL((head_bwd_kernel<1, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W, total); break;
+    case 2: hipLaunchKernelGGL((head_bwd_kernel<2, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W, total); break;
+    case 3: hipLaunchKernelGGL((head_bwd_kernel<3, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W, total); break;
+    default: hipLaunchKernelGGL((head_bwd_kernel<4, XB>), dim3(grid), dim3(256), 0, st, x, w, dl, dx, red, B, H, W, total); break;
   }
   DT_LAUNCH_CHECK();
   return DT_OK;
