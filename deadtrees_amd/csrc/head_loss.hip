@@ -142,8 +142,14 @@ extern "C" int dt_head_fwd_bf16(const void* x_bf16, const float* w, const float*
 static inline int head_bwd_tiles(int B, int H, int W) { return B * dt_cdiv(H, HEAD_TH) * dt_cdiv(W, HEAD_TW); }
 extern "C" int dt_head_bwd_rows(int B, int H, int W) { return dt_cdiv(head_bwd_tiles(B, H, W), HB_TPW); }
 
+#define HB_ZP 40                          // pitch of the zero-bordered copy of the tile's own dl (12 rows x 38 columns used)
+#define HB_ZN (12 * HB_ZP)
+
+#ifndef HB_LB
+#define HB_LB 4
+#endif
 template <int K, bool XB = false>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, HB_LB) void head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ dl, void* __restrict__ dx,
                                                        float* __restrict__ red, int B, int H, int W, int total_tiles) {
   constexpr int C = HEAD_CIN;
@@ -151,11 +157,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ 
   constexpr int MT = (NR + 15) / 16;        // 16-row M tiles of the dW GEMM
   constexpr int KS = (NR + 3) / 4;          // K steps of the dx GEMM
   constexpr int NW = K * 9 * C + K, NWP = (NW + 3) & ~3;
+  constexpr int NSTEP = HB_HH * (HB_HWP / 4), SPW = (NSTEP + 3) / 4;   // 90 K steps of the dW GEMM, <= 23 per wave
   static_assert(4 * MT * 64 * 5 <= HB_NPIX * C, "the cross-wave reduction image fits the x tile");
   __shared__ __attribute__((aligned(16))) float xt[HB_NPIX * C];   // [halo pixel][16 channels]: 16 j + c -> 64 distinct banks
-  __shared__ float dlt[K * HB_NPIX];
+  __shared__ float dlt[K * HB_NPIX];        // dl with its halo (dx reads the neighbours' pixels)
+  __shared__ float dlz[K * HB_ZN];          // the tile's OWN dl at (py + 2, px + 2) inside a border of zeros: the dW operand
+                                            // dl[hy - kh, hx - kw] needs no range test for any halo pixel / tap
   const int tiles_x = (W + HEAD_TW - 1) / HEAD_TW, tiles_y = (H + HEAD_TH - 1) / HEAD_TH;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: the K-step bookkeeping below runs on the SALU
   const int m = lane & 15, j = lane >> 4;
 
   // ---- per-lane constants.  dx: A = w^T (row c = m, k index kk = 4 s + j), B = dl at halo (py + 2 - kh, px + 2 - kw)
@@ -169,17 +179,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ 
     wA[s] = ok ? w[kk * C + m] : 0.f;
     boff[s] = k * HB_NPIX + (2 - tap / 3) * HB_HWP + (2 - tap % 3);
   }
-  // dW: A row (k, tap) = 16 mt + m at halo pixel (hy, hx): dl of output pixel (hy - kh, hx - kw) if that lies in the tile
-  int aoff[MT], akh[MT], akw[MT];
+  // dW: A row (k, tap) = 16 mt + m at halo pixel (hy, hx) = dlz[k][hy - kh + 2][hx - kw + 2]; rows past 9K read the
+  // always-zero corner dlz[0][0][0 .. 3] with a zero stride
+  int aoff[MT], amul[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int rg = 16 * mt + m;
     const bool ok = rg < NR;
     const int k = ok ? rg / 9 : 0, tap = ok ? rg % 9 : 0;
-    akh[mt] = ok ? tap / 3 : 1000;       // an invalid row never passes the range test
-    akw[mt] = tap % 3;
-    aoff[mt] = k * HB_NPIX + (1 - tap / 3) * HB_HWP + (1 - tap % 3);
+    aoff[mt] = ok ? k * HB_ZN + (2 - tap / 3) * HB_ZP + (2 - tap % 3) + j : 0;
+    amul[mt] = ok ? 1 : 0;
   }
+  const int xoff = j * C + m;
   f32x4 accw[MT];
   float asum[MT];
 #pragma unroll
@@ -187,33 +198,81 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ 
     accw[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     asum[mt] = 0.f;
   }
+  for (int i = t; i < K * HB_ZN; i += 256) dlz[i] = 0.f;   // the border stays zero; the interior is rewritten per tile
 
+  // ---- staging: the tile's global loads are issued as one batch into registers (a loop of load -> LDS store pairs
+  // would serialise 6 global latencies per tile), and the NEXT tile's batch is in flight while this tile is multiplied.
+  // Element e = t + 256 it: halo position packed once per thread (hy << 8 | hx; 255 = not an element)
+  constexpr int NXL = (HB_NPIX * (C / 4) + 255) / 256, NDL = (K * HB_NPIX + 255) / 256;
+  int xpos[NXL], dpos[NDL];
+#pragma unroll
+  for (int it = 0; it < NXL; ++it) {
+    const int pix = (t + it * 256) >> 2;
+    const int hy = pix / HB_HWP, hx = pix - hy * HB_HWP;
+    xpos[it] = (pix < HB_NPIX && hx < HEAD_TW + 2) ? (hy << 8 | hx) : (255 << 8 | 255);
+  }
+#pragma unroll
+  for (int it = 0; it < NDL; ++it) {
+    const int i = t + it * 256;
+    const int k = i / HB_NPIX, pix = i - k * HB_NPIX;
+    const int hy = pix / HB_HWP, hx = pix - hy * HB_HWP;
+    dpos[it] = (k < K && hx < HEAD_TW + 2) ? (k << 16 | hy << 8 | hx) : (255 << 8 | 255);
+  }
+  f32x4 rx[NXL];
+  float rd[NDL];
+  auto issue_loads = [&](int tile) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
+#pragma unroll
+    for (int it = 0; it < NXL; ++it) {
+      const int iy = oy0 - 1 + ((xpos[it] >> 8) & 255), ix = ox0 - 1 + (xpos[it] & 255);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)     // 255: beyond any image this kernel takes (host check)
+        v = head_load4<XB>(x, (((size_t)b * H + iy) * W + ix) * C + 4 * (t & 3));
+      rx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NDL; ++it) {
+      const int iy = oy0 - 1 + ((dpos[it] >> 8) & 255), ix = ox0 - 1 + (dpos[it] & 255);
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        v = dl[(((size_t)b * K + (dpos[it] >> 16)) * H + iy) * W + ix];
+      rd[it] = v;
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < NXL; ++it) {
+      const int i = t + it * 256;
+      if (i < HB_NPIX * (C / 4)) *reinterpret_cast<f32x4*>(xt + i * 4) = rx[it];   // pix * 16 + 4 q = 4 i
+    }
+#pragma unroll
+    for (int it = 0; it < NDL; ++it) {
+      const int i = t + it * 256;
+      if (i < K * HB_NPIX) {
+        dlt[i] = rd[it];
+        const int hy = (dpos[it] >> 8) & 255, hx = dpos[it] & 255;
+        if (hy >= 1 && hy <= HEAD_TH && hx >= 1 && hx <= HEAD_TW)   // output pixel (hy - 1, hx - 1) of this tile
+          dlz[(dpos[it] >> 16) * HB_ZN + (hy + 1) * HB_ZP + hx + 1] = rd[it];
+      }
+    }
+  };
+  const int tile0 = blockIdx.x * HB_TPW;
+  issue_loads(tile0);     // host: grid = ceil(total / HB_TPW), so every workgroup has a first tile
+#pragma unroll 1
   for (int ti = 0; ti < HB_TPW; ++ti) {
-    const int tile = blockIdx.x * HB_TPW + ti;
+    const int tile = tile0 + ti;
     if (tile >= total_tiles) break;     // uniform
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
     const int oy0 = ty * HEAD_TH, ox0 = tx * HEAD_TW;
-    if (ti > 0) __syncthreads();        // the previous tile's reads are done
-    for (int i = t; i < HB_NPIX * (C / 4); i += 256) {
-      const int q = i & 3, pix = i >> 2;
-      const int hy = pix / HB_HWP, hx = pix - hy * HB_HWP;
-      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (hx < HEAD_TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = head_load4<XB>(x, (((size_t)b * H + iy) * W + ix) * C + 4 * q);
-      *reinterpret_cast<f32x4*>(xt + pix * C + 4 * q) = v;
-    }
-    for (int i = t; i < K * HB_NPIX; i += 256) {
-      const int k = i / HB_NPIX, pix = i - k * HB_NPIX;
-      const int hy = pix / HB_HWP, hx = pix - hy * HB_HWP;
-      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
-      float v = 0.f;
-      if (hx < HEAD_TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        v = dl[(((size_t)b * K + k) * H + iy) * W + ix];
-      dlt[i] = v;
-    }
+    __syncthreads();                    // the previous tile's reads are done (first tile: the zero fill of dlz)
+    write_lds();
     __syncthreads();
+#if !(defined(HB_ABLATE) && HB_ABLATE == 3)   // throw-away measurement builds: 1 no dW loop, 2 no dx, 3 no staging after the first tile
+    if (ti + 1 < HB_TPW && tile + 1 < total_tiles) issue_loads(tile + 1);
+#endif
     // ---- dx: wave w owns tile rows 2w, 2w+1 = 4 groups of 16 pixels
+#if !(defined(HB_ABLATE) && HB_ABLATE == 2)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int py = 2 * wave + (g >> 1), px = (g & 1) * 16 + m;
@@ -232,20 +291,33 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const void* __restrict__ 
         }
       }
     }
-    // ---- dW / dbias: K steps s = wave, wave + 4, ... of the 90 (halo row hy = s / 9, columns 4 (s % 9) + j)
-    for (int s = wave; s < HB_HH * (HB_HWP / 4); s += 4) {
-      const int hy = s / (HB_HWP / 4), hx = 4 * (s - hy * (HB_HWP / 4)) + j;
-      const int hp = hy * HB_HWP + hx;
-      const float bv = xt[hp * C + m];
+#endif
+    // ---- dW / dbias: wave w takes the K steps s = SPW w .. of the 90 (halo row hy = s / 9, columns 4 (s % 9) + j): the step
+    // bookkeeping is scalar, a lane adds its constant to two scalar offsets, reads and multiplies
+    // (the opaque scalar zero keeps hipcc from hoisting the unrolled loop's 23 x 3 per-lane LDS addresses out of the tile
+    // loop: 200+ live registers and 2 waves per SIMD otherwise)
+    int zs = 0;
+    asm volatile("" : "+s"(zs));
+    int s = wave * SPW + zs, hy = s / (HB_HWP / 4), sx = s - hy * (HB_HWP / 4);
+#if !(defined(HB_ABLATE) && HB_ABLATE == 1)
+#pragma unroll 4
+    for (int it = 0; it < SPW; ++it) {
+      const bool live = s < NSTEP;                                   // uniform (the last wave has fewer steps)
+      const int zo = live ? hy * HB_ZP + 4 * sx : 0, xo = (live ? hy * HB_HWP + 4 * sx : 0) * C;
+      const float bv = xt[xo + xoff];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const bool ok = (unsigned)(hy - akh[mt]) < (unsigned)HEAD_TH && (unsigned)(hx - akw[mt]) < (unsigned)HEAD_TW;
-        const float av = dlt[ok ? aoff[mt] + hp : 0];
-        const float a = ok ? av : 0.f;
+        const float a = dlz[live ? aoff[mt] + amul[mt] * zo : 0];
         asum[mt] += a;
         accw[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, accw[mt], 0, 0, 0);
       }
+      ++s;
+      if (++sx == HB_HWP / 4) {
+        sx = 0;
+        ++hy;
+      }
     }
+#endif
   }
   // ---- one partial row per workgroup: the four waves' accumulators combined in a fixed order
   __syncthreads();

@@ -889,7 +889,9 @@ class UNetEngine:
         for i in range(4, -1, -1):
             blk, d = sp.decoder[i], S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
-            dy2 = bn_bwd(blk.conv2, g, d["z2"], d["y2"], virtual_act=d["z2"] is None, reduced=g_red)
+            # the ReLU mask is recomputed from y2 * scale + shift even where z2 was stored (same arithmetic as bn_act:
+            # identical mask, one tensor less to read in the reduce / apply passes)
+            dy2 = bn_bwd(blk.conv2, g, None, d["y2"], virtual_act=True, reduced=g_red)
             self._tr(f"D{i}.dy2", dy2)
             if d.get("z1") is not None:
                 wgrad(blk.conv2, d["z1"], None, 0, Hh, Ww, dy2)
@@ -999,7 +1001,7 @@ class UNetEngine:
         _lib.check(lib.dt_maxpool3x3s2_bwd_bf16(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
                    "dt_maxpool3x3s2_bwd_bf16")
         self._tr("gf1", gf1)
-        dy = bn_bwd(sp.stem, gf1, stem["z"], stem["y"])
+        dy = bn_bwd(sp.stem, gf1, None, stem["y"], virtual_act=True)
         self._tr("stem.dy", dy)
         stc = sp.stem
         if stem.get("s2d") is not None:
@@ -1156,7 +1158,7 @@ class UNetEngine:
             g = G.pop(blk.name)
             dev = g.device
             Hh, Ww = d["H"], d["W"]
-            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"])
+            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, None, d["y2"], virtual_act=True)
             del g
             self._wgrad(blk.conv2, grads, d["y1"], None, 0, B, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
             dz1 = torch.empty_like(d["y1"])
@@ -1289,8 +1291,8 @@ class UNetEngine:
                 S[f"D{i}"] = None
                 continue
             # conv2 + BN + ReLU (activation stored only for the last block)
-            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, d["z2"], d["y2"], virtual_act=d["z2"] is None,
-                               reduced=g_red)
+            # mask recomputed from y2 * scale + shift even where z2 was stored (identical to bn_act's; one read less)
+            dy2 = self._bn_bwd(blk.conv2, params, grads, bnws, g, None, d["y2"], virtual_act=True, reduced=g_red)
             if d.get("z1") is not None:
                 self._wgrad(blk.conv2, grads, d["z1"], None, 0, B, Hh, Ww, dy2)
             else:
@@ -1402,7 +1404,7 @@ class UNetEngine:
         gf1 = skip_grads[0]
         _lib.check(lib.dt_maxpool3x3s2_bwd(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
                    "dt_maxpool3x3s2_bwd")
-        dy = self._bn_bwd(sp.stem, params, grads, bnws, gf1, stem["z"], stem["y"])
+        dy = self._bn_bwd(sp.stem, params, grads, bnws, gf1, None, stem["y"], virtual_act=True)
         self._wgrad(sp.stem, grads, stem["x"], None, 0, B, stem["Hin"], stem["Win"], dy)
         self._join_side()
         if self.grad_hook:
