@@ -69,10 +69,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int p = rl; p < P; p += 16) {
+    // 8 independent loads per round (pure latency: <= 256 rows, one launch per BatchNorm layer)
+    double u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0, w1 = 0.0, w2 = 0.0;
+    int p = rl;
+    for (; p + 48 < P; p += 64) {
+      const float a0 = stats[(size_t)p * C + c], a1 = stats[(size_t)(p + 16) * C + c];
+      const float a2 = stats[(size_t)(p + 32) * C + c], a3 = stats[(size_t)(p + 48) * C + c];
+      const float b0 = stats[((size_t)P + p) * C + c], b1 = stats[((size_t)P + p + 16) * C + c];
+      const float b2 = stats[((size_t)P + p + 32) * C + c], b3 = stats[((size_t)P + p + 48) * C + c];
+      s1 += (double)a0; u1 += (double)a1; v1 += (double)a2; w1 += (double)a3;
+      s2 += (double)b0; u2 += (double)b1; v2 += (double)b2; w2 += (double)b3;
+    }
+    for (; p < P; p += 16) {
       s1 += (double)stats[(size_t)p * C + c];
       s2 += (double)stats[((size_t)P + p) * C + c];
     }
+    s1 = (s1 + u1) + (v1 + w1);
+    s2 = (s2 + u2) + (v2 + w2);
   }
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
@@ -443,11 +456,25 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* __restric
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int p = rl; p < P; p += 16) {
+  if (c < C) {
+    // 8 independent loads per round (these kernels are pure latency: <= 256 rows, one launch per BatchNorm layer)
+    double u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0, w1 = 0.0, w2 = 0.0;
+    int p = rl;
+    for (; p + 48 < P; p += 64) {
+      const float a0 = red[(size_t)p * C + c], a1 = red[(size_t)(p + 16) * C + c];
+      const float a2 = red[(size_t)(p + 32) * C + c], a3 = red[(size_t)(p + 48) * C + c];
+      const float b0 = red[((size_t)P + p) * C + c], b1 = red[((size_t)P + p + 16) * C + c];
+      const float b2 = red[((size_t)P + p + 32) * C + c], b3 = red[((size_t)P + p + 48) * C + c];
+      s1 += (double)a0; u1 += (double)a1; v1 += (double)a2; w1 += (double)a3;
+      s2 += (double)b0; u2 += (double)b1; v2 += (double)b2; w2 += (double)b3;
+    }
+    for (; p < P; p += 16) {
       s1 += (double)red[(size_t)p * C + c];
       s2 += (double)red[((size_t)P + p) * C + c];
     }
+    s1 = (s1 + u1) + (v1 + w1);
+    s2 = (s2 + u2) + (v2 + w2);
+  }
   sh[0][rl][cl] = s1;
   sh[1][rl][cl] = s2;
   __syncthreads();
