@@ -13,6 +13,17 @@ __device__ __forceinline__ void load8(const bf16x8* p, size_t i, float (&v)[8]) 
   for (int k = 0; k < 8; ++k) v[k] = (float)a[k];
 }
 
+// streaming form for tensors read for the last time (nontemporal; -DBN_NT=0 restores plain loads, see elementwise.hip)
+__device__ __forceinline__ void load8s(const bf16x8* p, size_t i, float (&v)[8]) {
+#if !defined(BN_NT) || BN_NT
+  const bf16x8 a = __builtin_nontemporal_load(p + i);
+#else
+  const bf16x8 a = p[i];
+#endif
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = (float)a[k];
+}
+
 // 8 consecutive per-channel fp32 coefficients (c % 8 == 0) as two 16-byte loads
 __device__ __forceinline__ void ldc8(const float* __restrict__ p, int c, float (&v)[8]) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(p + c), b = *reinterpret_cast<const f32x4*>(p + c + 4);
@@ -193,11 +204,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(
   }
   for (int64_t i = i0; i < n8; i += stride) {
     float g[8], yv[8];
-    load8(dout, i, g);
-    load8(y, i, yv);
+    load8s(dout, i, g);
+    load8s(y, i, yv);
     if (out_act) {
       float a[8];
-      load8(out_act, i, a);
+      load8s(out_act, i, a);
 #pragma unroll
       for (int k = 0; k < 8; ++k) g[k] = a[k] > 0.f ? g[k] : 0.f;
     } else if (act_scale) {
