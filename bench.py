@@ -24,6 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import deadtrees_amd  # noqa: E402,F401  (first: its import sets the HIP hardware-queue count before the runtime initialises)
 
 FLOP_PER_TILE_TRAIN = 186.53e9      # SURVEY §8d / BASELINE.md §2 (conv FLOPs fwd+bwd, 512x512x3, K=2); scaled by
 BYTES_PER_TILE_TRAIN = 924.3e6      # (size/512)^2 for other tile sizes.  ideal-fused fp32 algorithmic HBM bytes

@@ -558,7 +558,11 @@ class UNetEngine:
     def _side_stream(self, device):
         st = self._ws.get("side_stream")
         if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
+            # high priority = its own hardware queue.  ROCm deals streams round-robin onto GPU_MAX_HW_QUEUES (4) hardware
+            # queues; once an RCCL process group has created its streams a default-priority side stream lands on the
+            # queue of the main stream and the weight gradients serialise behind the chain they should run beside
+            # (measured with an RCCL group initialised, same box: 729 tiles/s -> 770; without a group 767 either way)
+            st = torch.cuda.Stream(device=device, priority=int(os.environ.get("DT_SIDE_PRIORITY", "-1")))
             self._ws["side_stream"] = st
         return st
 
@@ -581,6 +585,25 @@ class UNetEngine:
             ev = torch.cuda.Event()
             ev.record(side)
             main.wait_event(ev)
+
+    def _bucket_done(self, bucket):
+        """a contiguous range of the flat gradient buffer is complete: hand it to ``grad_hook`` (the data-parallel
+        all-reduce).  Its producers ran on the main stream (BatchNorm / head gradients) AND on the weight-gradient side
+        stream; instead of joining main <- side (which drains the overlap at every bucket) the hook is called with the
+        SIDE stream current, after that stream has been ordered behind main's work so far: the collective waits for
+        both, the main stream waits for nobody."""
+        if not self.grad_hook:
+            return
+        main = torch.cuda.current_stream()
+        side = self._ws.get("side_stream")
+        if side is None:
+            self.grad_hook(*bucket)
+            return
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self.grad_hook(*bucket)
 
     def mark_weights_changed(self):
         """call after writing the flat parameter buffer behind torch's back (fused optimiser step)"""
@@ -936,9 +959,7 @@ class UNetEngine:
             del dup
             self._tr(f"D{i}.g", g)
             S[f"D{i}"] = None
-        if self.grad_hook:
-            self._join_side()
-            self.grad_hook(*sp.buckets[0])
+        self._bucket_done(sp.buckets[0])
 
         for li in (3, 2, 1, 0):
             blocks = sp.layers[li]
@@ -992,9 +1013,8 @@ class UNetEngine:
                     self._tr(f"L{li}B{bi}.gin", gin)
                 g = gin
                 S[f"L{li}B{bi}"] = None
-            if li > 0 and self.grad_hook:
-                self._join_side()
-                self.grad_hook(*sp.buckets[4 - li])
+            if li > 0:
+                self._bucket_done(sp.buckets[4 - li])
 
         pl, stem = S["pool"], S["stem"]
         gf1 = skip_grads[0]
@@ -1336,9 +1356,7 @@ class UNetEngine:
                 _lib.check(lib.dt_upsample2x_bwd(_p(dup), _p(g), 0, B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd")
             del dup
             S[f"D{i}"] = None
-        if self.grad_hook:
-            self._join_side()
-            self.grad_hook(*sp.buckets[0])
+        self._bucket_done(sp.buckets[0])
 
         # g = gradient wrt f5 ; encoder layers in reverse
         for li in (3, 2, 1, 0):
@@ -1394,9 +1412,8 @@ class UNetEngine:
                     del dyd
                 g = gin
                 S[f"L{li}B{bi}"] = None
-            if li > 0 and self.grad_hook:
-                self._join_side()
-                self.grad_hook(*sp.buckets[4 - li])
+            if li > 0:
+                self._bucket_done(sp.buckets[4 - li])
 
         # ---- maxpool + stem
         pl = S["pool"]
