@@ -273,7 +273,7 @@ def train_leg(args, ctx, precision, B, headline):
         if overlapped:
             roof["measured_on"] = ("2 serial eager steps after the timed region (weight gradients on the main stream, "
                                    f"{1e3 * serial_step_s:.2f} ms per step): the timed steps run them on a second stream, "
-                                   "which overlaps kernel lifetimes; profiles/r02_bench_b32_serial_kernel_stats.csv is "
+                                   "which overlaps kernel lifetimes; profiles/r02_bench_b32_serial_kernel_stats_v2.csv is "
                                    "rocprofv3 of this command with DT_OVERLAP_WGRAD=0")
         if "wino" in name:
             # Winograd F(2x2,3x3): `achieved` keeps the contract's definition (ALGORITHMIC = direct-convolution FLOPs /

@@ -544,7 +544,7 @@ class UNetEngine:
                                      desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
                 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
             if mt.value == 8:     # the LDS-DMA staged 512-pixel kernel (conv_bf16_dma.hip)
-                name = f"conv3x3_bf16_dma_kernel<{'true' if in_ss else 'false'}>"
+                name = f"conv3x3_bf16_dma_kernel<{'true' if in_ss else 'false'}, {2 if desc.accumulate else 0}>"
             else:
                 name = (f"conv_fwd_bf16_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, "
                         f"{mt.value}, {'true' if in_ss else 'false'}>")
