@@ -462,3 +462,32 @@ def test_conv_bf16_dma_kernel_fused_bn_backward_sums(join):
         _set_dma(1)
     assert torch.equal(res[0][0], res[2][0])
     np.testing.assert_allclose(res[0][1].cpu().numpy(), res[2][1].cpu().numpy(), rtol=2e-5, atol=2e-3)
+
+
+@pytest.mark.parametrize("K,B,H,W", [(2, 2, 24, 40), (3, 1, 21, 37), (2, 1, 70, 130)])
+def test_head_backward_bf16(K, B, H, W):
+    """dt_head_bwd_bf16 (bf16 decoder activation in, bf16 gradient out, fp32 dW / dbias; MFMA kernel of head_loss.hip)
+    against fp64 on the same bf16-rounded activation: dx within one bf16 rounding, dW / dbias to fp32 accuracy"""
+    import ctypes as C
+    from deadtrees_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(10 * K + B)
+    xq, x64 = bf(torch.randn((B, 16, H, W), generator=g))
+    x64 = x64.requires_grad_(True)
+    w = (torch.randn((K, 16, 3, 3), generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = torch.zeros(K, dtype=torch.float64, requires_grad=True)
+    dl = torch.randn((B, K, H, W), generator=g)
+    F.conv2d(x64, w, b, padding=1).backward(dl.double())
+    w_ohwi = w.detach().permute(0, 2, 3, 1).contiguous().float().to(DEV)
+    dlg = dl.to(DEV)
+    dx = torch.empty_like(xq)
+    red = torch.empty(lib.dt_head_bwd_red_floats(B, H, W, 16, K), device=DEV)
+    dw, db = torch.empty(K * 9 * 16, device=DEV), torch.empty(K, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.dt_head_bwd_bf16(p(xq), p(w_ohwi), p(dlg), p(dx), p(red), B, H, W, 16, K, st), "dt_head_bwd_bf16")
+    _lib.check(lib.dt_head_bwd_finalize(p(red), lib.dt_head_bwd_rows(B, H, W), p(dw), p(db), 16, K, st), "dt_head_bwd_finalize")
+    close_bf16(to_nchw(dx), x64.grad)
+    ref_dw = w.grad.permute(0, 2, 3, 1).reshape(-1)
+    assert float((dw.cpu().double() - ref_dw).abs().max()) <= 1e-5 * float(ref_dw.abs().max())
+    assert float((db.cpu().double() - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max())

@@ -275,11 +275,13 @@ def test_upsample_bwd_and_layout():
     assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.to(DEV))).cpu(), x)
 
 
-@pytest.mark.parametrize("K", [2, 3])
-def test_head_forward_backward(K):
+@pytest.mark.parametrize("K,B,H,W", [(2, 2, 24, 40), (3, 2, 24, 40), (1, 3, 21, 37), (4, 1, 8, 32), (2, 1, 70, 130)])
+def test_head_forward_backward(K, B, H, W):
+    """K = 1..4 (1 / 2 / 2 / 3 row tiles and 3 / 5 / 7 / 9 K-steps of the MFMA backward), ragged right / bottom edges, tile
+    runs of a workgroup that cross image rows and images, fewer tiles than one workgroup takes"""
     ops = _ops()
     g = torch.Generator().manual_seed(K)
-    B, H, W, Cin = 2, 24, 40, 16
+    Cin = 16
     x = torch.randn((B, Cin, H, W), generator=g, dtype=torch.float64, requires_grad=True)
     w = (torch.randn((K, Cin, 3, 3), generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
     b = (torch.randn(K, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
