@@ -54,6 +54,7 @@ SIGNATURES = {
     "dt_winograd_weights": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_conv2d_winograd": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_winograd_weight_images": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, c_f]),
+    "dt_conv2d_winograd_affine": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_winograd_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),
     "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),

@@ -77,7 +77,9 @@ __device__ __forceinline__ void wn_dma16(const void* g, void* l) {
 }
 
 // EPI: 0 store (+ BatchNorm statistics, split outputs); 1 store + fused BatchNorm-backward sums (virtual activation);
-//      2 gradient join (out0 += ...); 3 join + BatchNorm-backward sums (stored activation)
+//      2 gradient join (out0 += ...); 3 join + BatchNorm-backward sums (stored activation);
+//      4 inference: out = relu(conv * scale + shift) (eval-mode BatchNorm + ReLU applied to the accumulators: the raw
+//        output is never stored and no elementwise pass follows); 5 the same with a residual: relu(conv * scale + shift + res)
 //
 // Persistent workgroups (one per CU): workgroup g walks the tiles xcd_remap(g + round * grid) — the n-tiles of one
 // spatial tile run at the same time on one XCD and share its L2 — as ONE sequence of steps (tile, 8-channel chunk).
@@ -388,8 +390,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
         b_sh = a.bnb.act_shift[n];
       }
     }
+    if constexpr (EPI >= 4) {
+      b_sc = a.bnb.act_scale[n];
+      b_sh = a.bnb.act_shift[n];
+    }
     const bool second = outp == a.out1 && a.cout_split > 0;
-    const bool join = EPI >= 2 && !second;   // split data gradients accumulate into out0 only
+    const bool join = (EPI == 2 || EPI == 3) && !second;   // split data gradients accumulate into out0 only
     // 32-bit byte offsets + buffer descriptors: a pixel outside the map gets WN_OOB -> its loads return 0 and its store
     // is dropped by the range check (no branches); y / act of the fused BatchNorm-backward forms share out0's layout
     const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, second ? a.obytes1 : a.obytes0, 0x00020000);
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
       // output transforms are computed; the scheduling fence keeps hipcc from hoisting all 256 accumulator reads
       unsigned off[16];
       int soff[16];
-      float prev[(EPI >= 2) ? 16 : 1], yv[(EPI == 1 || EPI == 3) ? 16 : 1], zv[(EPI == 3) ? 16 : 1];
+      float prev[(EPI == 2 || EPI == 3) ? 16 : 1], yv[(EPI == 1 || EPI == 3 || EPI == 5) ? 16 : 1], zv[(EPI == 3) ? 16 : 1];
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
         const int i = 4 * qr + ii;   // accumulator row m = (i & 3) + 8 (i >> 2) + 4 kh: tile row i >> 2, tile column (i & 3) + 4 kh
@@ -419,12 +425,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
           soff[4 * ii + e] = tile_base + py * row4 + px * ld4;
         }
       }
-      if constexpr (EPI >= 2) {
+      if constexpr (EPI == 2 || EPI == 3) {
 #pragma unroll
         for (int x = 0; x < 16; ++x)
           prev[x] = join ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rso, off[x], soff[x], 0)) : 0.f;
       }
-      if constexpr (EPI == 1 || EPI == 3) {
+      if constexpr (EPI == 1 || EPI == 3 || EPI == 5) {   // EPI 5: bnb.y is the residual tensor (layout of out0)
 #pragma unroll
         for (int x = 0; x < 16; ++x) yv[x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsy, off[x], soff[x], 0));
       }
@@ -451,7 +457,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
       for (int x = 0; x < 16; ++x) {
         const bool ok = off[x] != WN_OOB;
         float v = y[x];
-        if constexpr (EPI >= 2) v += prev[x];
+        if constexpr (EPI == 2 || EPI == 3) v += prev[x];
+        if constexpr (EPI >= 4) {   // the arithmetic of bn_act_kernel: mul, add (, + residual), ReLU that keeps NaN
+          v = v * b_sc + b_sh;
+          if constexpr (EPI == 5) v += yv[x];
+          v = v < 0.f ? 0.f : v;
+        }
         if constexpr (EPI == 3) {
           const float g = (ok && zv[x] > 0.f) ? v : 0.f;
           s1 += g;
@@ -633,7 +644,7 @@ extern "C" int dt_conv2d_winograd_stat_rows(const dt_conv_desc* d) {
 
 int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* src1, const float* u, float* out0,
                         float* out1, float* stats, const float* in_scale, const float* in_shift,
-                        const dt_bn_bwd_fuse* fuse, hipStream_t st) {
+                        const dt_bn_bwd_fuse* fuse, hipStream_t st, bool affine) {
   DT_REQUIRE(dt_conv2d_winograd_supported(d), "conv_winograd: layer shape not supported");
   DT_REQUIRE(d->Ho == d->Hin && d->Wo == d->Win, "conv_winograd: 3x3 stride 1 pad 1 keeps the map size");
   WinoArgs a;
@@ -659,13 +670,18 @@ int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* s
   a.obytes0 = (unsigned)ob0;
   a.ubytes = (unsigned)((size_t)16 * (d->C0 + d->C1) * d->Cout * 4);
   a.obytes1 = (unsigned)ob1;
-  const bool bnb = a.bnb.y != nullptr, join = d->accumulate != 0;
+  const bool bnb = !affine && a.bnb.y != nullptr, join = d->accumulate != 0;
   DT_REQUIRE(!bnb || stats != nullptr, "conv_winograd: fused BatchNorm-backward sums need the stats buffer");
+  DT_REQUIRE(!affine || (in_scale == nullptr && !join && d->cout_split == 0 && stats == nullptr),
+             "conv_winograd: the inference epilogue takes no input transform, join, split or statistics");
   DT_REQUIRE(!(in_scale != nullptr && bnb), "conv_winograd: no input transform on the BatchNorm-backward form");
   const int total = sp_tiles * a.n_tiles;
   a.P = wn_stat_rows(d, &a.pstats);       // rows of the statistics buffer (indexing stride of its two planes)
   dim3 g((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)), blk(256);   // persistent: one workgroup per CU
-  if (in_scale != nullptr && join) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 2>), g, blk, 0, st, a, total);
+  if (affine) {
+    if (a.bnb.y != nullptr) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 5>), g, blk, 0, st, a, total);
+    else hipLaunchKernelGGL((conv3x3_wino_kernel<false, 4>), g, blk, 0, st, a, total);
+  } else if (in_scale != nullptr && join) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 2>), g, blk, 0, st, a, total);
   else if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 0>), g, blk, 0, st, a, total);
   else if (!bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 0>), g, blk, 0, st, a, total);
   else if (bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 1>), g, blk, 0, st, a, total);
@@ -682,7 +698,20 @@ extern "C" int dt_conv2d_winograd(const dt_conv_desc* d, const float* src0, cons
   DT_REQUIRE(d->C1 == 0 || src1, "conv_winograd: src1 missing");
   DT_REQUIRE(d->cout_split == 0 || out1, "conv_winograd: out1 missing");
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_winograd: in_scale/in_shift must come together");
-  return dt_conv_wino_launch(d, src0, src1, u, out0, out1, stats, in_scale, in_shift, nullptr, (hipStream_t)stream);
+  return dt_conv_wino_launch(d, src0, src1, u, out0, out1, stats, in_scale, in_shift, nullptr, (hipStream_t)stream, false);
+}
+
+// inference form: out = relu(conv(src) * scale + shift [+ residual]) — eval-mode BatchNorm + ReLU (and the residual add of a
+// ResNet basic block) applied to the accumulators, the ATen chain conv2d -> batch_norm(eval) -> (add) -> relu_ in one
+// kernel; same arithmetic as dt_conv2d_winograd followed by dt_bn_act (bit-identical results)
+extern "C" int dt_conv2d_winograd_affine(const dt_conv_desc* d, const float* src0, const float* src1, const float* u,
+                                         float* out, const float* scale, const float* shift, const float* residual,
+                                         void* stream) {
+  DT_REQUIRE(d && src0 && u && out && scale && shift, "conv_winograd_affine: null pointer");
+  DT_REQUIRE(d->C1 == 0 || src1, "conv_winograd_affine: src1 missing");
+  DT_REQUIRE(d->cout_split == 0 && d->accumulate == 0, "conv_winograd_affine: no split outputs / joins");
+  dt_bn_bwd_fuse f{residual, nullptr, nullptr, scale, shift, nullptr};
+  return dt_conv_wino_launch(d, src0, src1, u, out, nullptr, nullptr, nullptr, nullptr, &f, (hipStream_t)stream, true);
 }
 
 // data gradient with the BatchNorm-backward sums of the layer the gradient belongs to fused into the epilogue: the
@@ -695,5 +724,5 @@ extern "C" int dt_conv2d_winograd_bn_bwd(const dt_conv_desc* d, const float* src
   DT_REQUIRE(d->mode0 == 0 && d->C1 == 0 && d->cout_split == 0, "conv_winograd_bn_bwd: plain 3x3 stride-1 data gradients only");
   DT_REQUIRE((d->accumulate != 0) == (fuse->act != nullptr),
              "conv_winograd_bn_bwd: gradient joins (accumulate) go with a stored activation, plain stores with a virtual one");
-  return dt_conv_wino_launch(d, src0, nullptr, u, out0, nullptr, red, nullptr, nullptr, fuse, (hipStream_t)stream);
+  return dt_conv_wino_launch(d, src0, nullptr, u, out0, nullptr, red, nullptr, nullptr, fuse, (hipStream_t)stream, false);
 }

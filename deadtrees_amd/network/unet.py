@@ -80,6 +80,9 @@ class UNetEngine:
         # being applied while conv2 / its weight gradient stage their input: the fused form costs those kernels 11-13 %
         # (one wave per SIMD: the staging instructions are not free behind the MFMAs), the extra pass 0.4 ms — measured 713 vs 704
         # tiles/s; DT_MATERIALIZE_Z1=0 restores the fused form (a gain with the direct kernels: +2 % in round 1)
+        # inference (eval mode, nothing saved): BatchNorm + ReLU (+ residual) in the Winograd epilogue, DT_FUSE_EVAL=0 = A/B
+        self._fuse_eval_opt = os.environ.get("DT_FUSE_EVAL", "1") != "0"
+        self._fuse_eval = False
         self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
         # the same for the decoder block outputs that feed a Winograd conv1 (716.6 vs 712.8 tiles/s)
         self._mat_z2 = os.environ.get("DT_MATERIALIZE_Z2", "1" if self.winograd else "0") != "0"
@@ -267,6 +270,28 @@ class UNetEngine:
                                       _p(z), B * H * W, Cc, int(relu), _stream()), "dt_bn_act")
         return z
 
+    def _conv_affine_eval(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, res=None):
+        """inference: relu(bn_eval(conv(x)) [+ res]) in ONE Winograd launch (dt_conv2d_winograd_affine) — no raw output, no
+        bn_act pass.  Returns the activation, or None when the layer is not a Winograd layer (caller: conv + bn_act)."""
+        if not self._fuse_eval or c.k != 3 or c.stride != 1 or c.pad != 1:
+            return None
+        C0 = src0.shape[-1]
+        C1 = 0 if src1 is None else src1.shape[-1]
+        desc = self._desc(B, Hin, Win, C0, C1, mode0, Hin, Win, c.cout, 3, 1, 1)
+        u = self._u(c)
+        if not self._use_wino(desc, u):
+            return None
+        scale, shift = self._ss(c, bnws)
+        if not self._affine_fresh:
+            _lib.check(self.lib.dt_bn_eval_affine(_p(params[c.g_off:c.g_off + c.cout]), _p(params[c.b_off:c.b_off + c.cout]),
+                                                  _p(bnstate[2 * c.bn_off: 2 * c.bn_off + c.cout]),
+                                                  _p(bnstate[2 * c.bn_off + c.cout: 2 * c.bn_off + 2 * c.cout]), BN_EPS,
+                                                  c.cout, _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
+        z = torch.empty((B, Hin, Win, c.cout), dtype=torch.float32, device=src0.device)
+        _lib.check(self.lib.dt_conv2d_winograd_affine(C.byref(desc), _p(src0), _p(src1), _p(u), _p(z), _p(scale),
+                                                      _p(shift), _p(res), _stream()), "dt_conv2d_winograd_affine")
+        return z
+
     def _const_vec(self, value: float, n: int, device) -> torch.Tensor:
         key = f"const_{value}"
         t = self._ws.get(key)
@@ -301,6 +326,8 @@ class UNetEngine:
                                                 bnstate._version, self._bn_epoch, bnws.data_ptr())
         self._affine_fresh = akey is not None and self._ws.get("affine_key") == akey
         self._ws["affine_key"] = akey
+        self._fuse_eval = (self._fuse_eval_opt and not training and not save and self.winograd
+                           and sp.decoder_kind not in ("resunet", "unetplusplus"))
         if save:
             # mean/invstd are needed by backward: keep a private copy target per forward
             bnws = torch.empty(4 * sp.n_bn_channels, dtype=torch.float32, device=dev)
@@ -328,6 +355,13 @@ class UNetEngine:
         for li, blocks in enumerate(sp.layers):
             for bi, blk in enumerate(blocks):
                 xin = cur
+                if self._fuse_eval and blk.conv1.stride == 1 and blk.down is None:
+                    z1 = self._conv_affine_eval(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw)
+                    out = None if z1 is None else self._conv_affine_eval(blk.conv2, params, bnstate, bnws, z1, None, 0, B,
+                                                                         ch, cw, res=xin)
+                    if out is not None:
+                        cur = out
+                        continue
                 y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw, training,
                                                         save_stats=save)
                 # z1 = relu(bn1(y1)) is virtual: conv2 applies it while staging y1 (A/B switch DT_MATERIALIZE_Z1:
@@ -376,6 +410,12 @@ class UNetEngine:
                 keep(f"D{i}", x=d, skip=skip, y1=y1, y2=y2, H=h1, W=w1)
                 d, dh, dw, d_ss = out, h2, w2, None
                 continue
+            if self._fuse_eval and d_ss is None:
+                z1 = self._conv_affine_eval(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win)
+                z2 = None if z1 is None else self._conv_affine_eval(blk.conv2, params, bnstate, bnws, z1, None, 0, B, Hin, Win)
+                if z2 is not None:
+                    d, dh, dw, d_ss = z2, Hin, Win, None
+                    continue
             y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training,
                                             in_ss=d_ss, save_stats=save)
             z1 = self._bn_act(y1, ss1) if (self._mat_z1 and blk.conv2.cout % 64 == 0) else None

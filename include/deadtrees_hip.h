@@ -86,6 +86,12 @@ int dt_conv2d_winograd_stat_rows(const dt_conv_desc* d);
 int dt_winograd_weights(const float* w_hwio, float* u, int Cin, int Cout, void* stream);
 int dt_conv2d_winograd(const dt_conv_desc* d, const float* src0, const float* src1, const float* u, float* out0,
                        float* out1, float* stats, const float* in_scale, const float* in_shift, void* stream);
+/* inference form (eval-mode BatchNorm): out = relu(conv(src) * scale + shift [+ residual]) — the ATen chain conv2d ->
+ * batch_norm(eval) -> (add) -> relu_ of a ResNet / decoder block (reference call site deployment/inference.py:60) in ONE
+ * kernel; scale / shift per output channel (dt_bn_eval_affine), residual (optional) in the layout of out.  Same
+ * arithmetic as dt_conv2d_winograd followed by dt_bn_act: bit-identical.  No split outputs, joins or statistics. */
+int dt_conv2d_winograd_affine(const dt_conv_desc* d, const float* src0, const float* src1, const float* u, float* out,
+                              const float* scale, const float* shift, const float* residual, void* stream);
 /* all eligible layers in one launch: int32 table rows (w_off, u_off, Cin, Cout, first_block), blocks of a layer =
  * ceil(Cout/64) * ceil(Cin/16); `weights` = the flat parameter buffer (forward images) or its dt_weight_images mode-0
  * image with Cin/Cout swapped (data-gradient images). */

@@ -177,3 +177,56 @@ def test_winograd_weight_gradient_matches_fp64_and_direct_kernel(B, H, W, C0, C1
     assert float((direct - want).abs().max()) <= 2e-5 * scale
     again = ops.conv2d_wgrad_winograd(nhwc(x), nhwc(dy), **kw).cpu().double()
     assert torch.equal(again, got)          # fixed-order reduction: run-to-run bit-identical
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,residual", [(2, 32, 32, 64, 0, 0, 64, True), (1, 34, 70, 128, 0, 0, 128, False),
+                                                            (2, 16, 24, 128, 64, 1, 64, False), (3, 17, 33, 64, 0, 0, 64, True)])
+def test_winograd_inference_epilogue_is_bit_identical_to_conv_plus_bn_act(B, H, W, C0, C1, mode0, Cout, residual):
+    """dt_conv2d_winograd_affine (eval-mode BatchNorm + ReLU (+ residual) applied to the accumulators) == dt_conv2d_winograd
+    followed by dt_bn_act, bit for bit: ragged edges, upsample + concat, residual add"""
+    import ctypes as C
+    from deadtrees_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 100 + H + Cout)
+    Hin, Win = (H, W) if mode0 == 0 else (2 * H, 2 * W)
+    x = torch.randn((B, H, W, C0), generator=g).to(DEV)
+    s1 = torch.randn((B, Hin, Win, C1), generator=g).to(DEV) if C1 else None
+    w = (torch.randn((3, 3, C0 + C1, Cout), generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5).to(DEV)
+    u = ops.winograd_weights(w)
+    scale = (1 + 0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    shift = (0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    res = torch.randn((B, Hin, Win, Cout), generator=g).to(DEV) if residual else None
+    y, _, _ = ops.conv2d_winograd(x, u, src1=s1, mode0=mode0)
+    want = ops.bn_act(y, scale, shift, res=res)
+    d = ops.conv_desc(B, Hin, Win, C0, C1, mode0, Cout, 3, 1, 1)
+    got = torch.empty_like(y)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.dt_conv2d_winograd_affine(C.byref(d), p(x), p(s1), p(u), p(got), p(scale), p(shift), p(res), st),
+               "dt_conv2d_winograd_affine")
+    assert torch.equal(got, want)
+
+
+def test_fused_inference_forward_is_bit_identical_to_the_unfused_one():
+    """UNetHIP.predict_classes / eval forward with the BatchNorm + ReLU (+ residual) epilogues (default) against the same
+    network with DT_FUSE_EVAL off: identical logits and class maps"""
+    from deadtrees_amd.network.unet import UNetHIP
+    m = UNetHIP(in_channels=3, classes=2)
+    m.reset_parameters(seed=3)
+    m.to(DEV).eval()
+    # non-trivial running statistics
+    g = torch.Generator().manual_seed(0)
+    m.bn_state.copy_((torch.rand(m.bn_state.shape, generator=g) * 0.5 + 0.25).to(DEV))
+    x = torch.randn((2, 3, 96, 160), generator=g).to(DEV)
+    eng = m.engine
+    assert eng._fuse_eval_opt
+    with torch.no_grad():
+        a = m(x).clone()
+        ca = m.predict_classes(x, dtype="uint8").clone()
+        eng._fuse_eval_opt = False
+        eng._ws.pop("affine_key", None)
+        b = m(x).clone()
+        cb = m.predict_classes(x, dtype="uint8").clone()
+        eng._fuse_eval_opt = True
+    assert torch.equal(a, b) and torch.equal(ca, cb)
