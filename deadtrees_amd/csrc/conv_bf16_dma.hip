@@ -359,15 +359,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
             }
           }
     }
-    // plain stores (bf16 staging: 512 x 72 x 2 B fit one operand buffer) pass the whole tile through the staging image at
-    // once — all eight waves write, one barrier pair; gradient joins (fp32 staging) take the two 256-pixel halves in turn
-    constexpr int NPASS = JOIN ? 2 : 1, PPX = 512 / NPASS, ITS_P = PPX / PER_IT;
-    static_assert(512 * OUT_PITCH * 2 <= DM_BUF, "the bf16 staging image of a whole tile fits one buffer");
 #pragma unroll 1
-    for (int hh = 0; hh < NPASS; ++hh) {
-      const int pbase = hh * PPX;
+    for (int hh = 0; hh < 2; ++hh) {
+      const int pbase = hh * 256;
       __syncthreads();   // the staging image is free: operand reads / the other half's stores are done
-      if (NPASS == 1 || hf == hh) {
+      if (hf == hh) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -375,15 +371,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const int mrow = (i & 3) + 8 * (i >> 2) + 4 * h;
-              const int pl = ((NPASS == 1 ? wave : lw) * 2 + m2) * 32 + mrow;
+              const int pl = (lw * 2 + m2) * 32 + mrow;
               if (join) st32[pl * OUTF_PITCH + 32 * j + r] = acc[m2][j][i];
               else st16[pl * OUT_PITCH + 32 * j + r] = (__bf16)acc[m2][j][i];
             }
       }
       __syncthreads();
       if (!JOIN || !join) {
-#pragma unroll 4
-        for (int it = 0; it < ITS_P; ++it) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
           const int pl = prow + it * PER_IT;
           const int oy = oy0 + (pbase + pl) / DM_TW, ox = ox0 + (pbase + pl) % DM_TW;
           if (oy < a.Ho && ox < a.Wo) {
