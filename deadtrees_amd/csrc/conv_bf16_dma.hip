@@ -196,11 +196,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
   // while chunk s is multiplied the DMA of chunk s+1 (possibly the next tile's first) fills the other buffer, so a
   // tile's epilogue and the next tile's first loads overlap.  One barrier per chunk + four per tile.
   if constexpr (TF) __syncthreads();   // the transform table
-#if defined(DM_ABLATE) && DM_ABLATE >= 3
-  if (false) {
-#else
   if (s_tile < total_tiles) {
-#endif
     stage_setup(s_tile);
 #pragma unroll
     for (int k = 0; k < 2 * DM_PPW; ++k) stage_piece(k, 0);
@@ -233,15 +229,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
     for (int c = 0; c < nchunks; ++c, ++step) {
       cur = (step & 1) * DM_BUF;
       const int nxt = DM_BUF - cur;
-#if !(defined(DM_ABLATE) && DM_ABLATE >= 3)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of this step have landed
-#endif
       __syncthreads();                                   // ... everybody's; and nobody still reads buffer `nxt`
-#if defined(DM_ABLATE) && (DM_ABLATE == 1 || DM_ABLATE >= 3)   // throw-away measurement build: no staging after the first step
-      const bool more = false;
-#else
       const bool more = s_tile < total_tiles;
-#endif
       const unsigned char* bufp = lds + cur;
       asm volatile("" : "+v"(qb));   // keep the address arithmetic below inside the loop (see qb)
       // 18 k-steps (tap, ks) of 4 MFMAs; the fragments of step t+1 are requested before the MFMAs of step t are issued
@@ -260,10 +250,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
           bv[j] = *reinterpret_cast<const bf16x8*>(bufp + (bbase ^ (ks << 5)) + tap * 4096 + j * 2048);
       };
       auto frag_mma = [&](const bf16x8 (&av)[2], const bf16x8 (&bv)[NT]) {
-#if defined(DM_ABLATE) && DM_ABLATE == 2     // throw-away measurement build: staging and fragment reads only
-        asm volatile("" ::"v"(av[0]), "v"(av[1]), "v"(bv[0]), "v"(bv[1]));
-        return;
-#endif
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -298,13 +284,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_dma_kernel(const ConvBfAr
       }
     }
 
-#if defined(DM_ABLATE) && DM_ABLATE == 4     // throw-away measurement build: no epilogue
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[m][j]));
-    continue;
-#endif
     // ---- epilogue (the arithmetic of conv_fwd_bf16_kernel): D col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*h.
     // The buffer just multiplied from (`cur`) is the staging image; the other one is receiving the next step's operands.
     // The tile's two 256-pixel halves (waves 0-3 / 4-7) pass through it one after the other, all 512 threads storing.

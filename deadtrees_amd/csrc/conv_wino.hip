@@ -317,23 +317,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     wn_static_for<0, 64>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       constexpr int p = k >> 2, j = k & 3, cur = p & 1;
-#if defined(WN_ABLATE) && WN_ABLATE == 3      // throw-away measurement build: staging and fragment reads only
-      asm volatile("" ::"v"(fa[cur][j]), "v"(fb[cur][j]));
-#else
       acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j], acc[p], 0, 0, 0);
-#endif
       if (j == 0 && p + 1 < 16) {
         fa[cur ^ 1] = *reinterpret_cast<const f32x4*>(Vc + (p + 1) * 2 * WN_PS);
         fb[cur ^ 1] = *reinterpret_cast<const f32x4*>(Uc + (p + 1) * 2 * WN_PS);
       }
-#if !(defined(WN_ABLATE) && WN_ABLATE == 1)   // 1: no staging after the prologue
-#if !(defined(WN_ABLATE) && WN_ABLATE == 5)   // 5: input loads + transform only
       if (j != 0 && k >= 22 && k < 34) {      // slots 22..31: the 8 weight planes of step s+1
         constexpr int wi = 3 * p + (j - 1) - 16;   // k = 22, 23, 25, 26, 27, 29, 30, 31 -> 0..7
         if (wi >= 0 && wi < 8) dma_plane(Un, wi);
       }
-#endif
-#if !(defined(WN_ABLATE) && WN_ABLATE == 4)   // 4: weight DMA only
       if (j != 0 && k < 22) {                 // slots 1..21: the 16 patch pixels of step s+2 (issued first: they come
         constexpr int li = 3 * p + (j - 1);   // from HBM, the weights from L2)
         if (li == 0) mark_valid(par_tag);
@@ -344,12 +336,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
       if (k >= 36 && k < 52) tf_b(SN{}, k - 36);
       if (k >= 52 && k < 56) transform_col(SN{}, k - 52);
       if (k >= 56 && k < 60) transform_row_write(Vn, k - 56);
-#endif
       if (k == 60) {
         advance_weights();
         advance_loads();
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
     });
     // this wave's weight planes of step s+1 (issued >= 32 MFMAs ago) and patch pixels of step s+2 (>= 42 MFMAs ago)
@@ -359,11 +349,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
 
   // ---- epilogue of one tile: output transform A^T M A (lane-local on the accumulators), stores, BatchNorm sums
   auto epilogue = [&](int round) {
-#if defined(WN_ABLATE) && WN_ABLATE == 2     // throw-away measurement build: no epilogue
-#pragma unroll
-    for (int p = 0; p < 16; ++p) asm volatile("" ::"v"(acc[p]));
-    return;
-#endif
     // everything derived from the tile index is wave-uniform; say so, or hipcc wraps each of the 64 buffer stores in a
     // waterfall loop (readfirstlane / compare / saveexec per store: the scalar-offset operand must be provably uniform)
     const int tile = __builtin_amdgcn_readfirstlane(tile_of_round(round));

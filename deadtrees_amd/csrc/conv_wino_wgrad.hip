@@ -291,29 +291,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
     ww_static_for<0, 64>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       constexpr int p = k >> 2, j = k & 3, cur = p & 1;
-#if defined(WW_ABLATE) && WW_ABLATE == 3      // throw-away measurement build: staging and fragment reads only
-      asm volatile("" ::"v"(fa[cur][j]), "v"(fb[cur][j]));
-#else
       acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j], acc[p], 0, 0, 0);
-#endif
       if (p + 1 < 16) {   // the next position's k-step j
         fa[cur ^ 1][j] = Vc[(p + 1) * 512 + j * 64];
         fb[cur ^ 1][j] = Wc[(p + 1) * 512 + j * 64];
       }
-#if !(defined(WW_ABLATE) && WW_ABLATE == 1)   // 1: no staging after the prologue
-#if !(defined(WW_ABLATE) && WW_ABLATE == 4)   // 4: transforms + LDS writes only (no loads)
       if (k == 1) prep_chunk(par_tag);                  // chunk c+2: offsets, then one load per slot
       if (k >= 2 && k < 22) load_one(par_tag, k - 2);
       if (k == 52) advance_tile();
-#endif
-#if !(defined(WW_ABLATE) && WW_ABLATE == 5)   // 5: loads only (no transforms / LDS writes)
       if (k >= 22 && k < 38) tf_a(SN{}, k - 22);
       if (k >= 23 && k < 39) tf_b(SN{}, k - 23);
       if (k >= 39 && k < 43) x_col(SN{}, k - 39);
       if (k >= 43 && k < 47) x_row_write(Vn, k - 43);
       if (k >= 47 && k < 51) g_write(SN{}, Wn, k - 47);
-#endif
-#endif
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of chunk c+2 (issued >= 58 MFMAs ago)

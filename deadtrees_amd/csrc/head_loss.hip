@@ -268,11 +268,8 @@ __global__ __launch_bounds__(256, HB_LB) void head_bwd_kernel(const void* __rest
     __syncthreads();                    // the previous tile's reads are done (first tile: the zero fill of dlz)
     write_lds();
     __syncthreads();
-#if !(defined(HB_ABLATE) && HB_ABLATE == 3)   // throw-away measurement builds: 1 no dW loop, 2 no dx, 3 no staging after the first tile
     if (ti + 1 < HB_TPW && tile + 1 < total_tiles) issue_loads(tile + 1);
-#endif
     // ---- dx: wave w owns tile rows 2w, 2w+1 = 4 groups of 16 pixels
-#if !(defined(HB_ABLATE) && HB_ABLATE == 2)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int py = 2 * wave + (g >> 1), px = (g & 1) * 16 + m;
@@ -291,7 +288,6 @@ __global__ __launch_bounds__(256, HB_LB) void head_bwd_kernel(const void* __rest
         }
       }
     }
-#endif
     // ---- dW / dbias: wave w takes the K steps s = SPW w .. of the 90 (halo row hy = s / 9, columns 4 (s % 9) + j): the step
     // bookkeeping is scalar, a lane adds its constant to two scalar offsets, reads and multiplies
     // (the opaque scalar zero keeps hipcc from hoisting the unrolled loop's 23 x 3 per-lane LDS addresses out of the tile
@@ -299,7 +295,6 @@ __global__ __launch_bounds__(256, HB_LB) void head_bwd_kernel(const void* __rest
     int zs = 0;
     asm volatile("" : "+s"(zs));
     int s = wave * SPW + zs, hy = s / (HB_HWP / 4), sx = s - hy * (HB_HWP / 4);
-#if !(defined(HB_ABLATE) && HB_ABLATE == 1)
 #pragma unroll 4
     for (int it = 0; it < SPW; ++it) {
       const bool live = s < NSTEP;                                   // uniform (the last wave has fewer steps)
@@ -317,7 +312,6 @@ __global__ __launch_bounds__(256, HB_LB) void head_bwd_kernel(const void* __rest
         ++hy;
       }
     }
-#endif
   }
   // ---- one partial row per workgroup: the four waves' accumulators combined in a fixed order
   __syncthreads();
