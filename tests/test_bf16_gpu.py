@@ -372,7 +372,9 @@ def _set_dma(mode):
 DMA_CASES = [  # B, H, W (stored size of source 0), C0, C1, mode0, Cout, split, transform
     (2, 32, 32, 64, 0, 0, 64, 0, False), (1, 34, 70, 512, 0, 0, 64, 0, True), (3, 17, 33, 32, 0, 0, 128, 0, False),
     (2, 16, 20, 64, 32, 1, 128, 0, True), (2, 16, 24, 128, 64, 1, 64, 0, False), (2, 40, 48, 64, 0, 0, 192, 64, False),
-    (1, 64, 64, 96, 0, 2, 64, 0, False)]
+    (1, 64, 64, 96, 0, 2, 64, 0, False),
+    # more tiles than persistent workgroups (640 / 320 > 256): BatchNorm partial sums accumulated over a workgroup's tiles
+    (40, 64, 64, 32, 0, 0, 128, 0, False), (40, 64, 64, 64, 0, 0, 64, 0, True)]
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,split,tf", DMA_CASES)
@@ -435,13 +437,14 @@ def test_conv_bf16_dma_kernel_is_bit_identical_to_the_register_staged_kernel(B, 
         np.testing.assert_allclose(a[2].cpu().numpy(), bq[2].cpu().numpy(), rtol=2e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("join", [False, True])
-def test_conv_bf16_dma_kernel_fused_bn_backward_sums(join):
+@pytest.mark.parametrize("join,B,H,W", [(False, 2, 40, 36), (True, 2, 40, 36), (False, 24, 64, 64), (True, 24, 64, 64)])
+def test_conv_bf16_dma_kernel_fused_bn_backward_sums(join, B, H, W):
     """dt_conv2d_bf16_bn_bwd on the DMA kernel: gradient bit-identical, BatchNorm-backward partial sums equal to the
-    register-staged kernel's per-channel totals (virtual activation / stored activation + gradient join)."""
+    register-staged kernel's per-channel totals (virtual activation / stored activation + gradient join); the large case
+    has 384 tiles for 256 persistent workgroups (sums carried over a workgroup's tiles, one row per workgroup)."""
     ops = _ops()
     g = torch.Generator().manual_seed(5 + join)
-    B, H, W, Cin, Cout = 2, 40, 36, 64, 128
+    Cin, Cout = 64, 128
     dy = torch.randn((B, H, W, Cin), generator=g).to(BF).to(DEV)
     wp = ops.pack_weights_bf16((torch.randn((3, 3, Cin, Cout), generator=g) * 0.05).to(DEV), dgrad=False)
     y = (torch.randn((B, H, W, Cout), generator=g) * 1.5 + 0.2).to(BF).to(DEV)
