@@ -146,8 +146,8 @@ extern "C" int dt_head_bwd_rows(int B, int H, int W) { return dt_cdiv(head_bwd_t
 #define HB_ZN (12 * HB_ZP)
 
 template <int K, bool XB = false>
-// 4 workgroups per CU (<= 128 VGPRs; 5 spills: measured 708 -> 927 us)
-__global__ __launch_bounds__(256, 4) void head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
+// K <= 2: 4 workgroups per CU (<= 128 VGPRs; 5 spill: measured 708 -> 927 us); K = 3 / 4 need 134 / 208 registers
+__global__ __launch_bounds__(256, K <= 2 ? 4 : (K == 3 ? 3 : 2)) void head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ dl, void* __restrict__ dx,
                                                        float* __restrict__ red, int B, int H, int W, int total_tiles) {
   constexpr int C = HEAD_CIN;
