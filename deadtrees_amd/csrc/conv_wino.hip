@@ -57,6 +57,7 @@ struct WinoArgs {
   int Cout, cout_split, accumulate;
   int tiles_x, tiles_y, n_tiles, P, nchunks;
   int pstats;                // 1: BatchNorm partial sums accumulated over the workgroup's tiles, ONE row per workgroup
+  int pack;                  // 1: maps of at most 8x8 pixels — FOUR images share a 16x16-pixel tile (one per 8x8 quadrant)
   unsigned bytes0, bytes1;   // sizes of the two sources (buffer descriptors: out-of-range loads return 0)
   unsigned obytes0, obytes1; // sizes of the two outputs
   unsigned ubytes;           // size of the transformed weights
@@ -88,7 +89,8 @@ __device__ __forceinline__ void wn_dma16(const void* g, void* l) {
 // sets: a full step of latency cover, across tile boundaries too), and the BatchNorm+ReLU / B^T d B transform / LDS
 // writes of step s+1.  One barrier per step; at a tile's last step the epilogue runs with the next tile's operands
 // already in flight.
-template <bool TF, int EPI>
+// PACK (compile time: the 16x16-map path pays nothing for it): see WinoArgs::pack
+template <bool TF, int EPI, bool PACK = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, const int total_tiles) {
   __shared__ __attribute__((aligned(1024))) float lds[4 * WN_BUF + 256 + (TF ? 2 * WN_TF_MAXC : 0)];
   float* Vb = lds;
@@ -119,15 +121,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     const bool live = round < my_tiles;
     const int tile = live ? tile_of_round(round) : 0;
     const int sp = tile / a.n_tiles;
-    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / tiles_per_img;
-    const int iy = 16 * ty - 1 + 2 * (wt >> 3), ix = 16 * tx - 1 + 2 * (wt & 7);
+    int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / tiles_per_img;
+    int iy = 16 * ty - 1 + 2 * (wt >> 3), ix = 16 * tx - 1 + 2 * (wt & 7);
+    bool img = live;
+    if constexpr (PACK) {   // quadrant (wt >> 5, (wt >> 2) & 1) of the 8x8 grid of Winograd tiles = image 4 sp + 2 qy + qx
+      b = 4 * sp + 2 * (wt >> 5) + ((wt >> 2) & 1);
+      iy = -1 + 2 * ((wt >> 3) & 3);
+      ix = -1 + 2 * (wt & 3);
+      img = live && b < a.B;
+    }
     const int Hs0 = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws0 = a.mode0 ? (a.Win >> 1) : a.Win;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int y = iy + i, x = ix + j;
-        const bool ok = live && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
+        const bool ok = img && (unsigned)y < (unsigned)a.Hin && (unsigned)x < (unsigned)a.Win;
         const int p0 = (b * Hs0 + (a.mode0 ? (y >> 1) : y)) * Ws0 + (a.mode0 ? (x >> 1) : x);
         const int p1 = (b * a.Hin + y) * a.Win + x;
         off0[4 * i + j] = ok ? (unsigned)(p0 * a.C0 + 2 * q) * 4u : WN_OOB;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     if constexpr (TF) {   // validity of the patch rows / columns as lane masks (SGPR pairs): pixel (i,j) = row i & column j
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        l_rmask[i] = __builtin_amdgcn_ballot_w64(live && (unsigned)(iy + i) < (unsigned)a.Hin);
+        l_rmask[i] = __builtin_amdgcn_ballot_w64(img && (unsigned)(iy + i) < (unsigned)a.Hin);
         l_cmask[i] = __builtin_amdgcn_ballot_w64((unsigned)(ix + i) < (unsigned)a.Win);
       }
     }
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     const int tile = __builtin_amdgcn_readfirstlane(tile_of_round(round));
     const int nt = tile % a.n_tiles, sp = tile / a.n_tiles;
     const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / tiles_per_img;
-    const int oy0 = 16 * ty, ox0 = 16 * tx, n0 = 64 * nt;
+    const int oy0 = PACK ? 0 : 16 * ty, ox0 = PACK ? 0 : 16 * tx, n0 = 64 * nt;
     const int n = n0 + 32 * wn + r;
     float* outp = a.out0;
     int ld = a.Cout, nn = n;
@@ -389,9 +398,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     // addressing: byte offset = [tile base + (row, column) of the output inside the wave's block: scalar, in the
     // buffer op's SGPR offset] + [the lane's own part: 1 VGPR]; a pixel outside the map gets WN_OOB in the VGPR part
     const int ld4 = __builtin_amdgcn_readfirstlane(ld * 4), row4 = __builtin_amdgcn_readfirstlane(a.Win * ld * 4);
-    const int tile_base = __builtin_amdgcn_readfirstlane(((b * a.Hin + oy0 + 8 * wave_m) * a.Win + ox0) * ld * 4);   // rows 8 wm .. 8 wm + 7
-    const unsigned lane_base = (unsigned)(8 * kh * ld4 + nn * 4);
-    const int xlane = ox0 + 8 * kh, ybase = oy0 + 8 * wave_m;
+    // packed small maps: the wave's 4 x 8 Winograd tiles are the quadrants (wm, 0 | 1) = images 4 sp + 2 wm + kh, each from
+    // its pixel (0, 0); otherwise rows 8 wm .. 8 wm + 7 of the tile, columns 8 kh ..
+    const int img_px4 = __builtin_amdgcn_readfirstlane(a.Hin * a.Win * ld * 4);
+    const int tile_base = __builtin_amdgcn_readfirstlane(
+        PACK ? (4 * sp + 2 * wave_m) * img_px4 : ((b * a.Hin + oy0 + 8 * wave_m) * a.Win + ox0) * ld * 4);
+    const unsigned lane_base = (unsigned)((PACK ? kh * img_px4 : 8 * kh * ld4) + nn * 4);
+    const int xlane = PACK ? 0 : ox0 + 8 * kh, ybase = PACK ? 0 : oy0 + 8 * wave_m;
+    const bool img_ok = !PACK || 4 * sp + 2 * wave_m + kh < a.B;
 #pragma unroll
     for (int qr = 0; qr < 4; ++qr) {
       // 4 accumulator rows (4 Winograd tiles x 4 pixels) at a time: the reads of this quarter are in flight while its
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int py = 2 * (i >> 2) + (e >> 1), px = 2 * (i & 3) + (e & 1);
-          const bool ok = ybase + py < a.Hin && xlane + px < a.Win;
+          const bool ok = img_ok && ybase + py < a.Hin && xlane + px < a.Win;
           off[4 * ii + e] = ok ? lane_base : WN_OOB;
           soff[4 * ii + e] = tile_base + py * row4 + px * ld4;
         }
@@ -615,8 +629,11 @@ extern "C" int dt_conv2d_winograd_supported(const dt_conv_desc* d) {
 
 // rows of the partial-sum buffer: one per workgroup when every tile of a workgroup has the same channel block
 // (32 % n_tiles == 0 with the xcd-aware tile order), one per spatial tile otherwise
+// maps of at most 8x8 pixels (layer 4 of a 256x256 tile): four images per 16x16-pixel tile instead of one with 3/4 padding
+static inline int wn_pack(const dt_conv_desc* d) { return d->Hin <= 8 && d->Win <= 8; }
+
 static int wn_stat_rows(const dt_conv_desc* d, int* pstats) {
-  const int sp = d->B * dt_cdiv(d->Ho, 16) * dt_cdiv(d->Wo, 16), nt = d->Cout / 64;
+  const int sp = wn_pack(d) ? dt_cdiv(d->B, 4) : d->B * dt_cdiv(d->Ho, 16) * dt_cdiv(d->Wo, 16), nt = d->Cout / 64;
   const long total = (long)sp * nt;
   *pstats = nt > 0 && (32 % nt) == 0;
   return *pstats ? (int)(total < WN_MAX_WGS ? total : WN_MAX_WGS) : sp;
@@ -641,7 +658,8 @@ int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* s
   a.tiles_x = dt_cdiv(d->Wo, 16);
   a.tiles_y = dt_cdiv(d->Ho, 16);
   a.n_tiles = d->Cout / 64;
-  a.P = d->B * a.tiles_x * a.tiles_y;
+  a.pack = wn_pack(d);
+  a.P = a.pack ? dt_cdiv(d->B, 4) : d->B * a.tiles_x * a.tiles_y;
   const int sp_tiles = a.P;
   a.nchunks = (d->C0 + d->C1) / 8;
   const size_t px0 = (size_t)d->B * (d->mode0 ? (d->Hin / 2) * (size_t)(d->Win / 2) : (size_t)d->Hin * d->Win);
@@ -663,15 +681,24 @@ int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* s
   const int total = sp_tiles * a.n_tiles;
   a.P = wn_stat_rows(d, &a.pstats);       // rows of the statistics buffer (indexing stride of its two planes)
   dim3 g((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)), blk(256);   // persistent: one workgroup per CU
-  if (affine) {
-    if (a.bnb.y != nullptr) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 5>), g, blk, 0, st, a, total);
-    else hipLaunchKernelGGL((conv3x3_wino_kernel<false, 4>), g, blk, 0, st, a, total);
-  } else if (in_scale != nullptr && join) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 2>), g, blk, 0, st, a, total);
-  else if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_kernel<true, 0>), g, blk, 0, st, a, total);
-  else if (!bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 0>), g, blk, 0, st, a, total);
-  else if (bnb && !join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 1>), g, blk, 0, st, a, total);
-  else if (!bnb && join) hipLaunchKernelGGL((conv3x3_wino_kernel<false, 2>), g, blk, 0, st, a, total);
-  else hipLaunchKernelGGL((conv3x3_wino_kernel<false, 3>), g, blk, 0, st, a, total);
+  // epilogue form (see the kernel) x input transform x packed small maps
+  const int epi = affine ? (a.bnb.y != nullptr ? 5 : 4) : (bnb ? 1 : 0) + (join ? 2 : 0);
+  const bool tf = in_scale != nullptr;
+  DT_REQUIRE(!tf || epi == 0 || epi == 2, "conv_winograd: the input transform goes with the plain / join epilogues only");
+#define WN_LAUNCH(TFv, EPIv)                                                                              \
+  do {                                                                                                    \
+    if (a.pack) hipLaunchKernelGGL((conv3x3_wino_kernel<TFv, EPIv, true>), g, blk, 0, st, a, total);      \
+    else hipLaunchKernelGGL((conv3x3_wino_kernel<TFv, EPIv, false>), g, blk, 0, st, a, total);            \
+  } while (0)
+  if (tf && epi == 2) WN_LAUNCH(true, 2);
+  else if (tf) WN_LAUNCH(true, 0);
+  else if (epi == 0) WN_LAUNCH(false, 0);
+  else if (epi == 1) WN_LAUNCH(false, 1);
+  else if (epi == 2) WN_LAUNCH(false, 2);
+  else if (epi == 3) WN_LAUNCH(false, 3);
+  else if (epi == 4) WN_LAUNCH(false, 4);
+  else WN_LAUNCH(false, 5);
+#undef WN_LAUNCH
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

@@ -30,7 +30,11 @@ CASES = [  # B, H, W (stored size of source 0), C0, C1, mode0, Cout, split, tran
     (2, 16, 20, 64, 32, 1, 128, 0, True), (2, 16, 24, 128, 64, 1, 64, 0, False), (2, 40, 48, 64, 0, 0, 192, 64, False),
     (2, 16, 16, 16, 0, 0, 64, 0, False), (1, 5, 7, 16, 16, 0, 64, 0, True),
     # persistent workgroups over several rounds (490 and 735 tiles on 256 CUs), ragged edges, tile-boundary prefetch
-    (5, 100, 100, 16, 0, 0, 128, 0, True), (5, 50, 50, 16, 16, 1, 192, 64, False)]
+    (5, 100, 100, 16, 0, 0, 128, 0, True), (5, 50, 50, 16, 16, 1, 192, 64, False),
+    # maps of at most 8x8 pixels: four images share a 16x16-pixel tile (layer 4 of a 256x256 sub-tile); batch not a
+    # multiple of 4, ragged maps, fused input transform, upsample + concat from 4x4, split outputs + join
+    (6, 8, 8, 64, 0, 0, 64, 0, False), (5, 7, 6, 128, 0, 0, 128, 0, True), (3, 4, 4, 64, 32, 1, 64, 0, False),
+    (7, 8, 8, 64, 0, 0, 192, 64, False), (70, 8, 8, 32, 0, 0, 128, 0, False)]
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,split,tf", CASES)
@@ -83,14 +87,14 @@ def test_winograd_weight_transform():
     assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("join", [False, True])
-def test_winograd_fused_bn_backward_sums_match_the_direct_kernel(join):
+@pytest.mark.parametrize("join,B,H,W", [(False, 3, 100, 84), (True, 3, 100, 84), (False, 9, 8, 8), (True, 6, 7, 8)])
+def test_winograd_fused_bn_backward_sums_match_the_direct_kernel(join, B, H, W):
     """dt_conv2d_winograd_bn_bwd against dt_conv2d_bn_bwd: the gradient within the Winograd tolerance, the
     BatchNorm-backward partial sums (virtual activation / stored activation + gradient join) equal per channel; ragged
-    map, several rounds of the persistent workgroups."""
+    map, several rounds of the persistent workgroups; small maps packed four images to a tile."""
     ops = _ops()
     g = torch.Generator().manual_seed(7 + join)
-    B, H, W, Cin, Cout = 3, 100, 84, 32, 128
+    Cin, Cout = 32, 128
     dy = torch.randn((B, H, W, Cin), generator=g).to(DEV)
     w = (torch.randn((3, 3, Cin, Cout), generator=g) * 0.05).to(DEV)
     y = (torch.randn((B, H, W, Cout), generator=g) * 1.5 + 0.2).to(DEV)
@@ -180,7 +184,8 @@ def test_winograd_weight_gradient_matches_fp64_and_direct_kernel(B, H, W, C0, C1
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,residual", [(2, 32, 32, 64, 0, 0, 64, True), (1, 34, 70, 128, 0, 0, 128, False),
-                                                            (2, 16, 24, 128, 64, 1, 64, False), (3, 17, 33, 64, 0, 0, 64, True)])
+                                                            (2, 16, 24, 128, 64, 1, 64, False), (3, 17, 33, 64, 0, 0, 64, True),
+                                                            (10, 8, 8, 128, 0, 0, 128, True), (5, 6, 8, 64, 0, 0, 64, False)])
 def test_winograd_inference_epilogue_is_bit_identical_to_conv_plus_bn_act(B, H, W, C0, C1, mode0, Cout, residual):
     """dt_conv2d_winograd_affine (eval-mode BatchNorm + ReLU (+ residual) applied to the accumulators) == dt_conv2d_winograd
     followed by dt_bn_act, bit for bit: ragged edges, upsample + concat, residual add"""
