@@ -6,13 +6,15 @@ Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launche
 Rank 0 prints ONE JSON line.  Workload = BASELINE.json configs[1]: reference U-Net (smp Unet/resnet34
 topology), fp32, batch 32 per GPU, 512x512x3 synthetic tiles, losses GDICE+FOCAL, clip 0.5, Adam 3e-4.
 
-`roofline`: the dominant kernel (most GPU time among the convolution launches) timed live with HIP
-events on the launch stream; achieved = algorithmic conv FLOPs of those launches / their summed
-duration; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  Since round 2 the 3x3 stride-1 layers run as
-Winograd F(2x2,3x3) (conv_wino.hip): algorithmic FLOPs stay the direct-convolution count, so `frac` can exceed 1;
-`mfma_issued_frac` is the share of the matrix peak the kernel's own (16/36) multiplies use.  The whole fp32 network is
-compute-bound (176 FLOP/B), so the binding roof is "mfma"; the HBM fraction of the step is reported
-next to it in `hbm_frac_step`.
+`roofline`: the dominant kernel (most GPU time among the convolution launches) timed live with HIP events on the launch
+stream.  `achieved` / `frac` are fractions of a ROOF, <= 1 by construction: for the Winograd F(2x2,3x3) kernels (every
+3x3 stride-1 layer with wide enough channels since round 2) `achieved` is the rate of the multiplies the kernel ISSUES on
+the matrix cores (16 of every 36 algorithmic ones) and `frac` = that / 157.3 TFLOP/s (fp32 MFMA peak,
+MI355X_MICROARCH.md); the direct-convolution-equivalent rate (algorithmic FLOPs of SURVEY 8d / duration, which exceeds
+the peak) is kept beside it as `direct_equiv_TFLOPs`.  `roofline.kernels` lists every kernel family of the step (time
+per step, share, binding roof, fraction of it), taken from two serial eager steps after the timed region.  The whole
+fp32 network is compute-bound (176 FLOP/B), so the binding roof is "mfma"; the HBM fraction of the step is reported next
+to it in `whole_net.hbm_frac_step`.
 `cpu_baseline`: the oracle port of the reference's CPU path (oracle/train_ref.py) timed on this box's host
 cores on a bounded sample (B=2, 512x512, a few steps) — rank 0, N=1 only.
 """
@@ -52,6 +54,12 @@ def main():
                          "(uint8 tiles -> uint8 class maps, BASELINE configs[4] per-GPU leg)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this process becomes a launcher — it starts the N ranks as a CHILD
+        # torch.distributed.run (never exec) before anything here has touched the GPU, relays their output and rank 0's
+        # JSON line, and exits with the child's code
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -59,8 +67,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         "(python bench.py --gpus N does that by itself when no launcher is involved)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback on the product path")
     ndev = torch.cuda.device_count()
@@ -110,7 +118,7 @@ def main():
             im.reset_parameters(seed=0)
             leg = infer_bench(ia, im.to(dev), dev, world, rank, distributed, as_leg=True)
             out.setdefault("legs", {})["infer_fp32_256"] = {k: leg[k] for k in ("metric", "value", "unit", "ms_per_step", "km2_per_hour",
-                                                                                  "tiler_inclusive", "config", "whole_net")}
+                                                                                  "tiler_inclusive", "config", "whole_net", "roofline")}
             del im
         except Exception as e:  # noqa: BLE001
             out.setdefault("legs", {})["infer_fp32_256"] = {"error": f"{type(e).__name__}: {e}"}
@@ -120,6 +128,34 @@ def main():
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n: int) -> int:
+    """launcher half of `python bench.py --gpus N`: N ranks under torch.distributed.run on 127.0.0.1 as a child process"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    line_json = None
+    for line in proc.stdout:
+        st = line.strip()
+        if st.startswith("{") and '"metric"' in st:
+            line_json = st                  # rank 0's result: printed last, alone
+        else:
+            sys.stderr.write(line)          # everything else the ranks said (warnings, tracebacks)
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        rc = 1
+    return rc
 
 
 def cpu_baseline(args):
@@ -145,6 +181,73 @@ def cpu_baseline(args):
                       f"{steps} timed steps after 1 warm-up, median; single thread: 2 timed steps)"}
 
 
+WINO_ISSUED = 16.0 / 36.0     # Winograd F(2x2,3x3): multiplies issued on the matrix cores per algorithmic multiply
+
+
+def kernel_family(name: str):
+    """profiled launch name -> (family label, binding roof, issued-multiply share of the algorithmic FLOPs, peak, unit)"""
+    bf = "bf16" in name
+    mf = 2500.0 if bf else PEAK_FP32_TFLOPS
+    if name.startswith("conv3x3_wino_wgrad"):
+        return ("Winograd F(2x2,3x3) weight gradient + its split-K reductions", "mfma", WINO_ISSUED, mf, "TFLOP/s")
+    if name.startswith("conv3x3_wino_kernel"):
+        return ("Winograd F(2x2,3x3) forward / data gradient", "mfma", WINO_ISSUED, mf, "TFLOP/s")
+    if name.startswith("conv3x3_bf16_dma"):
+        return ("bf16 LDS-DMA convolution forward / data gradient", "mfma", 1.0, mf, "TFLOP/s")
+    if name.startswith("conv_wgrad_bf16"):
+        return ("bf16 weight gradient + split-K final", "mfma", 1.0, mf, "TFLOP/s")
+    if name.startswith("conv_fwd_bf16"):
+        return ("bf16 register-staged convolution (Cout <= 32, stride 2, 1x1, stem)", "mfma", 1.0, mf, "TFLOP/s")
+    if name.startswith("conv_wgrad"):
+        return ("direct weight gradient + split-K reductions (Cout <= 32, stride 2, 1x1, stem)", "mfma", 1.0, mf, "TFLOP/s")
+    if name.startswith("conv_fwd"):
+        return ("direct convolution forward / data gradient (Cout <= 32, stride 2, 1x1, stem)", "mfma", 1.0, mf, "TFLOP/s")
+    if name.startswith("bn_bwd_apply"):
+        return ("bn_bwd_apply (BatchNorm + ReLU backward, elementwise)", "hbm", 0.0, PEAK_HBM_GBS, "GB/s")
+    if name.startswith("bn_bwd_reduce"):
+        return ("bn_bwd_reduce (BatchNorm backward sums not fused into a producer)", "hbm", 0.0, PEAK_HBM_GBS, "GB/s")
+    if name.startswith("bn_act"):
+        return ("bn_act (BatchNorm apply + ReLU + residual, materialised activations)", "hbm", 0.0, PEAK_HBM_GBS, "GB/s")
+    if name.startswith("head_"):
+        return ("segmentation head forward / backward", "hbm", 0.0, PEAK_HBM_GBS, "GB/s")
+    return (name, "hbm", 0.0, PEAK_HBM_GBS, "GB/s")
+
+
+def roofline_tables(prof, prof_steps, share_s):
+    """per-launch records (name, algorithmic FLOPs, start, end, algorithmic bytes) of `prof_steps` serial steps ->
+    (per-kernel-name aggregate, family table sorted by time, issued matrix-core FLOPs per step, direct-equivalent FLOPs
+    per step).  Every `frac` is a fraction of the family's binding roof: issued multiplies / MFMA peak, or algorithmic
+    bytes / HBM peak."""
+    by_name, fam = {}, {}
+    for name, flops, a, b, nbytes in prof:
+        t = a.elapsed_time(b) * 1e-3
+        r = by_name.setdefault(name, [0.0, 0.0, 0, 0.0])
+        r[0] += t; r[1] += flops; r[2] += 1; r[3] += nbytes
+        label, bound, issued, peak, unit = kernel_family(name)
+        f = fam.setdefault(label, {"t": 0.0, "fl": 0.0, "n": 0, "nb": 0.0, "bound": bound, "issued": issued, "peak": peak, "unit": unit})
+        f["t"] += t; f["fl"] += flops; f["n"] += 1; f["nb"] += nbytes
+    table, issued_step, direct_step = [], 0.0, 0.0
+    for label, f in sorted(fam.items(), key=lambda kv: -kv[1]["t"]):
+        if f["t"] <= 0.0:
+            continue
+        row = {"family": label, "bound": f["bound"], "launches_per_step": round(f["n"] / prof_steps, 1),
+               "ms_per_step": round(1e3 * f["t"] / prof_steps, 3), "avg_launch_us": round(1e6 * f["t"] / f["n"], 1),
+               "share_of_step": round((f["t"] / prof_steps) / share_s, 4), "peak": f["peak"], "unit": f["unit"]}
+        if f["bound"] == "mfma":
+            direct = f["fl"] / f["t"] / 1e12
+            row["achieved"] = round(direct * f["issued"], 2)
+            if f["issued"] != 1.0:
+                row["direct_equiv_TFLOPs"] = round(direct, 2)
+            issued_step += f["fl"] * f["issued"] / prof_steps
+            direct_step += f["fl"] / prof_steps
+            row["hbm_GBps_algorithmic"] = round(f["nb"] / f["t"] / 1e9, 1)
+        else:
+            row["achieved"] = round(f["nb"] / f["t"] / 1e9, 1)
+        row["frac"] = round(row["achieved"] / f["peak"], 4)
+        table.append(row)
+    return by_name, table, issued_step, direct_step
+
+
 def train_leg(args, ctx, precision, B, headline):
     """one timed training configuration -> result dict (the bench.py JSON contract keys + roofline block)"""
     import torch
@@ -163,6 +266,7 @@ def train_leg(args, ctx, precision, B, headline):
     tr = HipTrainer(model, lr=3e-4, clip=0.5, losses=("GDICE", "FOCAL"), distributed=distributed,
                     precision=precision, graph=use_graph)
     tr.broadcast_parameters(0)
+    nparams = model.flat_params.numel()
     img, mask = synth_batch(B, S, S, 3, 2, seed=1234 + rank)
     img, mask = img.to(dev), mask.to(dev)   # inputs resident in HBM before the timed region
 
@@ -183,7 +287,7 @@ def train_leg(args, ctx, precision, B, headline):
     # overlap and a per-kernel duration is no longer that kernel's own time.  Like the graph-replay case the per-kernel
     # events therefore come from two SERIAL eager steps after the timed region (same kernels, same shapes, one stream).
     overlapped = bool(getattr(model.engine, "overlap_wgrad", False)) and precision == "fp32"
-    model.engine.profile = None if (use_graph or overlapped) else prof   # graph replays run no Python hooks: see below
+    model.engine.profile = None   # the timed steps run without per-launch events; the roofline tables come from below
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -196,25 +300,25 @@ def train_leg(args, ctx, precision, B, headline):
     dt = torch.tensor([wall], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    wall_rank = wall
     wall = float(dt)
     serial_step_s = None
-    if use_graph or overlapped:
-        # per-kernel events for the roofline block come from two EAGER, single-stream steps after the timed region (same
-        # kernels, same shapes; the timed steps above were graph replays / had the weight gradients on a second stream)
-        tr.use_graph = False
-        model.engine.overlap_wgrad = False
+    # per-kernel events for the roofline block come from two EAGER, single-stream steps after the timed region (same
+    # kernels, same shapes; the timed steps above were graph replays / had the weight gradients on a second stream)
+    tr.use_graph = False
+    model.engine.overlap_wgrad = False
+    tr.step(img, mask)
+    torch.cuda.synchronize()
+    model.engine.profile = prof
+    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    p0.record()
+    for _ in range(2):
         tr.step(img, mask)
-        torch.cuda.synchronize()
-        model.engine.profile = prof
-        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        p0.record()
-        for _ in range(2):
-            tr.step(img, mask)
-        p1.record()
-        torch.cuda.synchronize()
-        serial_step_s = float(p0.elapsed_time(p1)) * 1e-3 / 2
-        model.engine.profile = None
-        model.engine.overlap_wgrad = overlapped
+    p1.record()
+    torch.cuda.synchronize()
+    serial_step_s = float(p0.elapsed_time(p1)) * 1e-3 / 2
+    model.engine.profile = None
+    model.engine.overlap_wgrad = overlapped
     # PCIe-inclusive rate (never `value`): the batch arrives in pinned host memory every step (fp32 image + int64
     # mask, what the reference's loader hands to Lightning) on a copy stream, overlapped with the previous step
     pcie = None
@@ -247,49 +351,45 @@ def train_leg(args, ctx, precision, B, headline):
     ms_per_step = 1e3 * wall / args.steps
 
     # ---- roofline of the dominant conv kernel (rank 0's launches)
-    prof_steps = 2 if (use_graph or overlapped) else args.steps
-    step_s = float(e0.elapsed_time(e1)) * 1e-3 / args.steps
-    share_s = serial_step_s if (overlapped and serial_step_s) else step_s   # the step the profiled launches belong to
-    agg = {}
-    for name, flops, a, b, nbytes in prof:
-        t = a.elapsed_time(b) * 1e-3
-        r = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
-        r[0] += t
-        r[1] += flops
-        r[2] += 1
-        r[3] += nbytes
+    prof_steps = 2
+    share_s = serial_step_s            # the (serial) step the profiled launches belong to
+    agg, kernels, issued_step, direct_step = roofline_tables(prof, prof_steps, share_s)
     roof = None
-    conv_time = sum(r[0] for r in agg.values())
-    if agg:
-        name, (t, fl, n, nb) = max(agg.items(), key=lambda kv: kv[1][0])
-        ach = fl / t / 1e12
-        kpeak = 2500.0 if "bf16" in name else PEAK_FP32_TFLOPS
+    conv_names = {k: v for k, v in agg.items() if kernel_family(k)[1] == "mfma" and "(+" not in k}   # single-kernel brackets
+    conv_time = sum(r[0] for k, r in agg.items() if k.startswith(("conv_fwd", "conv3x3_wino_kernel", "conv3x3_bf16_dma")))
+    if conv_names:
+        name, (t, fl, n, nb) = max(conv_names.items(), key=lambda kv: kv[1][0])
+        _, _, issued, kpeak, _ = kernel_family(name)
+        direct = fl / t / 1e12
+        ach = direct * issued           # multiplies the kernel issues on the matrix cores per second
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": kpeak,
                 "unit": "TFLOP/s", "frac": round(ach / kpeak, 4), "traffic": None,
                 "launches": n, "avg_launch_ms": round(1e3 * t / n, 4),
                 "algorithmic_bytes_per_launch": round(nb / n), "algorithmic_flops_per_launch": round(fl / n),
                 "hbm_GBps_algorithmic": round(nb / t / 1e9, 1),
                 "share_of_step": round((t / prof_steps) / share_s, 4)}
-        if overlapped:
-            roof["measured_on"] = ("2 serial eager steps after the timed region (weight gradients on the main stream, "
-                                   f"{1e3 * serial_step_s:.2f} ms per step): the timed steps run them on a second stream, "
-                                   "which overlaps kernel lifetimes; profiles/r02_bench_b32_serial_kernel_stats_v2.csv is "
-                                   "rocprofv3 of this command with DT_OVERLAP_WGRAD=0")
-        if "wino" in name:
-            # Winograd F(2x2,3x3): `achieved` keeps the contract's definition (ALGORITHMIC = direct-convolution FLOPs /
-            # duration), so it can exceed the matrix peak; the kernel ISSUES 16/36 of them on the matrix cores
-            roof["algorithm"] = "Winograd F(2x2,3x3): 16 MFMA multiplies per 36 algorithmic ones"
-            roof["mfma_issued_TFLOPs"] = round(ach * 16.0 / 36.0, 2)
-            roof["mfma_issued_frac"] = round(ach * 16.0 / 36.0 / kpeak, 4)
-        # HBM bytes per launch from the PMC passes (profiles/traffic.json: FETCH_SIZE x2 correction for wide
-        # coalesced reads on gfx950 + WRITE_SIZE, separate rocprofv3 --pmc runs of this command)
+        if issued != 1.0:
+            roof["algorithm"] = ("Winograd F(2x2,3x3): 16 MFMA multiplies per 36 algorithmic ones; achieved / frac count the "
+                                 "ISSUED multiplies (a fraction of the matrix peak), direct_equiv_TFLOPs the algorithmic ones")
+            roof["direct_equiv_TFLOPs"] = round(direct, 2)
+            roof["issued_flops_per_launch"] = round(fl * issued / n)
+        if overlapped or use_graph:
+            roof["measured_on"] = ("2 serial eager steps after the timed region (one stream, "
+                                   f"{1e3 * serial_step_s:.2f} ms per step): the timed steps " +
+                                   ("run the weight gradients on a second stream, which overlaps kernel lifetimes" if overlapped
+                                    else "are HIP-graph replays (no per-launch events)") +
+                                   "; profiles/ holds rocprofv3 --kernel-trace --stats of the same serial steps")
+        # HBM bytes per launch from the PMC passes (profiles/traffic.json: separate rocprofv3 --pmc runs of this command,
+        # per-access-shape corrections from scripts/ubench/pmc_calib — see profiles/README.md)
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 roof["traffic"] = json.load(open(tfile)).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 pass
+        roof["kernels"] = kernels
     per_gpu_tiles_s = B * args.steps / wall * (S / 512.0) ** 2   # 512x512-equivalent tiles for the FLOP/byte model
+    step_wall_s = wall / args.steps
     peak_tf = PEAK_FP32_TFLOPS if precision == "fp32" else 2500.0   # dense bf16 MFMA peak
     bytes_per_tile = BYTES_PER_TILE_TRAIN if precision == "fp32" else 462.2e6
     out = {
@@ -303,12 +403,33 @@ def train_leg(args, ctx, precision, B, headline):
                    "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
         "loss": round(float(loss), 6), "hip_graph": use_graph,
         "pcie_inclusive_tiles_per_s": None if pcie is None else round(pcie, 2),
-        "whole_net": {"tflops": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12, 2),
-                      "mfma_frac": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12 / peak_tf, 4),
+        # whole step: the multiplies all convolution kernels ISSUE per step (profiled launches: Winograd layers count 16/36
+        # of their algorithmic FLOPs) / the timed step = the fraction of the matrix peak the step really uses; the
+        # direct-convolution-equivalent rate (SURVEY 8d's 186.53 GFLOP per tile) beside it is NOT a roofline fraction
+        "whole_net": {"mfma_issued_TFLOPs": round(issued_step / step_wall_s / 1e12, 2),
+                      "mfma_issued_frac": round(issued_step / step_wall_s / 1e12 / peak_tf, 4),
+                      "direct_equiv_TFLOPs": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12, 2),
+                      "direct_equiv_over_mfma_peak": round(per_gpu_tiles_s * FLOP_PER_TILE_TRAIN / 1e12 / peak_tf, 4),
+                      "profiled_conv_flops_per_step_over_model": round(direct_step / (B * (S / 512.0) ** 2 * FLOP_PER_TILE_TRAIN), 4),
                       "hbm_frac_step": round(per_gpu_tiles_s * bytes_per_tile / 1e9 / PEAK_HBM_GBS, 4),
                       "conv_fwd_dgrad_share_of_step": round((conv_time / prof_steps) / share_s, 4)},
         "roofline": roof,
     }
+    if distributed:
+        # N > 1 evidence: the collective really spans `world` ranks (an all-reduce of ones must return N), the spread of
+        # the per-rank step times, and the gradient bytes each rank hands to the bucketed all-reduce per step
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        lo = torch.tensor([wall_rank], dtype=torch.float64, device=dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        out["rccl_ranks"] = int(round(float(ones)))
+        out["dist_backend"] = dist.get_backend()
+        out["ms_per_step_rank_min"] = round(1e3 * float(lo) / args.steps, 3)
+        out["ms_per_step_rank_max"] = round(1e3 * float(hi) / args.steps, 3)
+        out["allreduce_bytes_per_step"] = int(4 * nparams) if world > 1 else 0
+        out["allreduce_buckets"] = 5
     # free this leg's buffers (saved activations, graph pool) before the next leg allocates its own
     del tr, model, img, mask
     import gc
@@ -418,6 +539,37 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
                  "km2_per_hour": round(world * km2_ortho / per_ortho * 3600.0, 1),
                  "what": "uint8 raster H2D + block split + normalise/forward/argmax + block merge on the device + uint8 map D2H, pageable host arrays",
                  "foreground_fraction": round(float(merged.mean()), 4)}
+    # roofline of the forward pass: per-launch events of two more (eager, single-stream) batches
+    roof = None
+    if not use_graph and rank == 0:
+        prof = []
+        step()
+        torch.cuda.synchronize()
+        model.engine.profile = prof
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        q0.record()
+        for _ in range(2):
+            step()
+        q1.record()
+        torch.cuda.synchronize()
+        model.engine.profile = None
+        ser_s = float(q0.elapsed_time(q1)) * 1e-3 / 2
+        agg, kernels, issued_step, direct_step = roofline_tables(prof, 2, ser_s)
+        convs = {k: v for k, v in agg.items() if kernel_family(k)[1] == "mfma"}
+        if convs:
+            name, (t, fl, n, nb) = max(convs.items(), key=lambda kv: kv[1][0])
+            _, _, issued, kpeak, _ = kernel_family(name)
+            direct = fl / t / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(direct * issued, 2), "peak": kpeak, "unit": "TFLOP/s",
+                    "frac": round(direct * issued / kpeak, 4), "traffic": None, "launches": n,
+                    "avg_launch_ms": round(1e3 * t / n, 4), "share_of_step": round((t / 2) / ser_s, 4),
+                    "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(nb / n),
+                    "measured_on": f"2 eager batches with per-launch events after the timed region ({1e3 * ser_s:.2f} ms per batch)",
+                    "whole_pass_mfma_issued_frac": round(issued_step / (wall / args.steps) / 1e12 / PEAK_FP32_TFLOPS, 4)
+                    if args.precision == "fp32" else None,
+                    "kernels": kernels}
+            if issued != 1.0:
+                roof["direct_equiv_TFLOPs"] = round(direct, 2)
     tiles_s = B * world * args.steps / wall
     km2_per_tile = (S * 0.20002 / 1000.0) ** 2          # pixel 0.20002 m (scripts/computestats_inference.py:57-59)
     fwd_flop = 62.59e9 * (S / 512.0) ** 2
@@ -428,8 +580,9 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
            "config": {"workload": f"tiled inference leg: uint8 {S}x{S}x4 sub-tiles, batch {B}/GPU, fused normalise + "
                                   "forward + uint8 argmax", "global_batch": B * world, "parallelism": f"dp{world}"},
            "km2_per_hour": round(tiles_s * km2_per_tile * 3600.0, 1),
-           "whole_net": {"tflops": round(tiles_s / world * fwd_flop / 1e12, 2),
-                         "mfma_frac": round(tiles_s / world * fwd_flop / 1e12 / PEAK_FP32_TFLOPS, 4)},
+           "whole_net": {"direct_equiv_TFLOPs": round(tiles_s / world * fwd_flop / 1e12, 2),
+                         "direct_equiv_over_mfma_peak": round(tiles_s / world * fwd_flop / 1e12 / PEAK_FP32_TFLOPS, 4)},
+           "roofline": roof,
            "tiler_inclusive": tiler,
            "foreground_pixels": int(out.sum()), "hip_graph": use_graph,
            "pcie_inclusive_tiles_per_s_per_gpu": None if pcie is None else round(pcie, 1)}

@@ -205,14 +205,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   auto tf_b = [&](auto set_tag, int i) {
     if constexpr (TF) {
       constexpr int SET = decltype(set_tag)::value;
-      f32x2 v = tf_v[i & 1];
-      v[0] = __builtin_fmaxf(v[0], tf_lo);
-      v[1] = __builtin_fmaxf(v[1], tf_lo);
-      const unsigned long long m = drm[SET][i >> 2] & dcm[SET][i & 3];   // a padded pixel was loaded as exactly 0 and stays 0
-      float o0, o1;
-      asm volatile("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %5, %6, %4"
-                   : "=&v"(o0), "=&v"(o1)
-                   : "v"(d[SET][i][0]), "v"(v[0]), "s"(m), "v"(d[SET][i][1]), "v"(v[1]));
+      const f32x2 v = tf_v[i & 1];
+      // ReLU that keeps NaN like torch.relu / bn_act (v_max would return the non-NaN operand): keep v where the pixel is
+      // real AND NOT (v < floor) — an ordered compare, false for NaN — else 0 (a padded pixel was loaded as exactly 0 and
+      // stays 0; a source-1 chunk has the floor -inf: nothing is below it).  v_cmp + v_cndmask per element: the VALU count
+      // of the v_max form; the mask algebra runs on the scalar unit.
+      const unsigned long long m = drm[SET][i >> 2] & dcm[SET][i & 3];
+      // !(floor > v) is true for NaN; one asm block: the keep-mask never leaves VCC
+      float o0 = v[0], o1 = v[1];
+      asm volatile("v_cmp_ngt_f32 vcc, %2, %0\n\ts_and_b64 vcc, vcc, %3\n\tv_cndmask_b32 %0, 0, %0, vcc\n\t"
+                   "v_cmp_ngt_f32 vcc, %2, %1\n\ts_and_b64 vcc, vcc, %3\n\tv_cndmask_b32 %1, 0, %1, vcc"
+                   : "+v"(o0), "+v"(o1)
+                   : "s"(tf_lo), "s"(m)
+                   : "vcc");
       d[SET][i][0] = o0;
       d[SET][i][1] = o1;
     }

@@ -191,14 +191,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
   auto tf_b = [&](auto set_tag, int i) {
     if constexpr (TF) {
       constexpr int SET = decltype(set_tag)::value;
-      f32x2 v = tf_v[i & 1];
-      v[0] = __builtin_fmaxf(v[0], tf_lo);
-      v[1] = __builtin_fmaxf(v[1], tf_lo);
+      const f32x2 v = tf_v[i & 1];
+      // NaN-keeping ReLU (see conv_wino.hip tf_b): real pixel AND NOT (v < floor) -> v, else 0
       const unsigned long long m = xrm[SET][i >> 2] & xcm[SET][i & 3];
-      float o0, o1;
-      asm volatile("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %5, %6, %4"
-                   : "=&v"(o0), "=&v"(o1)
-                   : "v"(dx[SET][i][0]), "v"(v[0]), "s"(m), "v"(dx[SET][i][1]), "v"(v[1]));
+      // !(floor > v) is true for NaN; one asm block: the keep-mask never leaves VCC
+      float o0 = v[0], o1 = v[1];
+      asm volatile("v_cmp_ngt_f32 vcc, %2, %0\n\ts_and_b64 vcc, vcc, %3\n\tv_cndmask_b32 %0, 0, %0, vcc\n\t"
+                   "v_cmp_ngt_f32 vcc, %2, %1\n\ts_and_b64 vcc, vcc, %3\n\tv_cndmask_b32 %1, 0, %1, vcc"
+                   : "+v"(o0), "+v"(o1)
+                   : "s"(tf_lo), "s"(m)
+                   : "vcc");
       dx[SET][i][0] = o0;
       dx[SET][i][1] = o1;
     }

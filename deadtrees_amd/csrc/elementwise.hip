@@ -505,12 +505,8 @@ int dt_bn_bwd_finish_sums(float* red, int P, int C, float* dgamma, float* dbeta,
 }
 
 // the gradient and the raw output are read for the LAST time by this pass: nontemporal loads (same-box A/B: fp32 step
-// +0.4 %, bf16 neutral; -DBN_NT=0 restores plain loads)
-#if !defined(BN_NT) || BN_NT
+// +0.4 %, bf16 neutral)
 #define BN_LD(p) __builtin_nontemporal_load(p)
-#else
-#define BN_LD(p) (*(p))
-#endif
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const f32x4* __restrict__ dout, const f32x4* __restrict__ out_act, const f32x4* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,

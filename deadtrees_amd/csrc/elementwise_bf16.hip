@@ -13,13 +13,9 @@ __device__ __forceinline__ void load8(const bf16x8* p, size_t i, float (&v)[8]) 
   for (int k = 0; k < 8; ++k) v[k] = (float)a[k];
 }
 
-// streaming form for tensors read for the last time (nontemporal; -DBN_NT=0 restores plain loads, see elementwise.hip)
+// streaming form for tensors read for the last time (nontemporal loads, see elementwise.hip)
 __device__ __forceinline__ void load8s(const bf16x8* p, size_t i, float (&v)[8]) {
-#if !defined(BN_NT) || BN_NT
   const bf16x8 a = __builtin_nontemporal_load(p + i);
-#else
-  const bf16x8 a = p[i];
-#endif
 #pragma unroll
   for (int k = 0; k < 8; ++k) v[k] = (float)a[k];
 }

@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, K <= 2 ? 4 : (K == 3 ? 3 : 2)) void head_bwd_k
     for (int it = 0; it < NXL; ++it) {
       const int iy = oy0 - 1 + ((xpos[it] >> 8) & 255), ix = ox0 - 1 + (xpos[it] & 255);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)     // 255: beyond any image this kernel takes (host check)
+      // non-elements (sentinel 0xffff) load nothing whatever the image size: their LDS slots must be exact zeros
+      if (xpos[it] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
         v = head_load4<XB>(x, (((size_t)b * H + iy) * W + ix) * C + 4 * (t & 3));
       rx[it] = v;
     }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, K <= 2 ? 4 : (K == 3 ? 3 : 2)) void head_bwd_k
     for (int it = 0; it < NDL; ++it) {
       const int iy = oy0 - 1 + ((dpos[it] >> 8) & 255), ix = ox0 - 1 + (dpos[it] & 255);
       float v = 0.f;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      if ((dpos[it] & 0xffff) != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
         v = dl[(((size_t)b * K + (dpos[it] >> 16)) * H + iy) * W + ix];
       rd[it] = v;
     }

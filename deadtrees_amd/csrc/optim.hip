@@ -60,7 +60,7 @@ extern "C" int dt_sumsq(const float* g, int64_t n, double* partial, void* stream
 
 __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ partial, int rows,
                                                         float max_norm, float gscale, float* norm,
-                                                        float* clipcoef) {
+                                                        float* clipcoef, int32_t* skip) {
   __shared__ double sh[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < rows; i += 256) s += partial[i];
@@ -77,14 +77,17 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
     float c = max_norm > 0.f ? max_norm / (nrm + 1e-6f) : 1.f;
     if (c > 1.f) c = 1.f;
     clipcoef[0] = c * gscale;
+    // a NaN/Inf anywhere in the gradient (e.g. through BatchNorm statistics of a channel that overflowed while the loss
+    // stayed finite) would reach every parameter through the clip coefficient: drop the update instead
+    if (skip && !(nrm == nrm && fabsf(nrm) != INFINITY)) skip[0] = 1;
   }
 }
 
 extern "C" int dt_clip_coef(const double* partial, int rows, float max_norm, float gscale, float* norm,
-                            float* clipcoef, void* stream) {
+                            float* clipcoef, int32_t* skip_flag, void* stream) {
   DT_REQUIRE(partial && norm && clipcoef && rows > 0, "clip_coef: bad args");
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, rows, max_norm, gscale,
-                     norm, clipcoef);
+                     norm, clipcoef, skip_flag);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -174,11 +177,11 @@ __global__ void adam_advance_kernel(double* __restrict__ t, const int32_t* __res
   hyper[2] = (float)(1.0 - pow(b2, te));
 }
 
-extern "C" int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_dev, float beta1, float beta2,
+extern "C" int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_dev, double beta1, double beta2,
                                float* hyper, void* stream) {
   DT_REQUIRE(t_dev && lr_dev && hyper, "adam_advance: bad args");
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, t_dev, skip_flag, lr_dev,
-                     (double)beta1, (double)beta2, hyper);
+                     beta1, beta2, hyper);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

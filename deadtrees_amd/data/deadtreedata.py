@@ -70,6 +70,35 @@ def train_transform_device(tiles_u8_nhwc: torch.Tensor, mask: torch.Tensor, lu: 
     return img, mask, lu
 
 
+_TRAIN_RNG = np.random.default_rng()
+
+
+def train_transform(image: np.ndarray, mask: Optional[np.ndarray] = None, masks=None):
+    """The reference's module-level ``train_transform`` (deadtreedata.py:128-146, an albumentations ``Compose``) as a
+    callable on ONE sample: HWC uint8 ``image`` (+ ``mask`` or a list ``masks``, as the reference's ``transform`` passes
+    them, :165-176) -> ``{"image": CHW f32 tensor, "mask": ..., "masks": [...]}`` with the same random flip / rot90 /
+    brightness-contrast draw for image and label maps.  Runs ``train_transform_device`` on a batch of one — the HIP
+    augmentation kernels; there is no CPU path (raises without a HIP device)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("deadtrees_amd train_transform runs the HIP augmentation kernels: no HIP device, no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    c = image.shape[-1]
+    maps = ([] if mask is None else [mask]) + list(masks or [])
+    tiles = torch.from_numpy(np.ascontiguousarray(image))[None].to(dev)
+    geo, bc = draw_train_params(1, _TRAIN_RNG)
+    geo, bc = geo.to(dev), bc.to(dev)
+    from .. import ops
+    img = ops.augment_normalize_u8(tiles, geo, bc, MEAN, STD, c).permute(0, 3, 1, 2)[0].contiguous()
+    outs = [ops.augment_labels(torch.from_numpy(np.ascontiguousarray(m))[None].to(dev).long(), geo)[0].to(
+        torch.from_numpy(np.asarray(m)).dtype) for m in maps]
+    out = {"image": img}
+    if mask is not None:
+        out["mask"] = outs[0]
+    if masks is not None:
+        out["masks"] = outs[(0 if mask is None else 1):]
+    return out
+
+
 class _SyntheticLoader:
     def __init__(self, n_batches, batch_size, size, in_channels, classes, seed, wrap_main, device, with_distmap):
         self.n, self.bs, self.size, self.c, self.k = n_batches, batch_size, size, in_channels, classes

@@ -182,7 +182,7 @@ class SemSegment(_Base):
             use_dist = distmaps_on_device(mask, logits.shape[1])   # loader attached none: HIP EDT on the labels
         loss, parts, err = seg_loss(logits, mask, use_dist, self.loss_names, alpha=self.alpha)
         self.label_error = err
-        self._label_errors.append(err)
+        self._note_label_error(err)
         self.last_parts = parts
         self.log(f"{stage}/dice_loss", parts["dice_loss"], on_step=False, on_epoch=True)
         if use_dist is not None:
@@ -200,9 +200,20 @@ class SemSegment(_Base):
         else:
             logits, mask = self._as_logits_labels(y_hat, y)
             _, parts, err = seg_loss(logits.detach(), mask, None, [n for n in self.loss_names if not n.startswith("BOUNDARY")])
-            self._label_errors.append(err)
+            self._note_label_error(err)
         self.log(f"{stage}/dice", parts["dice"], on_step=False, on_epoch=True)
         self.log(f"{stage}/dice_with_bg", parts["dice_with_bg"], on_step=False, on_epoch=True)
+
+    def _note_label_error(self, err):
+        """collect a step's device flag; the list is folded into one device scalar every 256 entries (no host sync), so
+        a training-only run without validation epochs cannot grow it without bound"""
+        self._label_errors.append(err)
+        if len(self._label_errors) >= 256:
+            self._label_errors = [torch.stack([e.reshape(()) for e in self._label_errors]).max()]
+
+    def training_epoch_end(self, outputs=None):
+        """Lightning hook: evaluate the epoch's label flags (the reference asserts per step, losses.py:129)"""
+        self._check_labels()
 
     def _check_labels(self):
         """the lazily evaluated assert of class2one_hot (losses.py:129): one host sync per epoch instead of two per step"""

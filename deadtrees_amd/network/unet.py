@@ -105,6 +105,36 @@ class UNetEngine:
             self._ws[name] = t
         return t
 
+    # ---- per-launch profiling (bench.py's roofline table): `self.profile` is None in production; as a list it receives
+    # (kernel / family name, algorithmic FLOPs, start event, end event, algorithmic HBM bytes) per bracketed launch group
+    def _pb(self):
+        if self.profile is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def _pe(self, e0, name: str, flops: float, nbytes: float):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.profile.append((name, float(flops), e0, e1, float(nbytes)))
+
+    @staticmethod
+    def _conv_work(desc, elt: int = 4):
+        """(algorithmic FLOPs, algorithmic HBM bytes) of a convolution / its weight gradient described by `desc`:
+        2 k^2 Cin Cout per output pixel; stored input(s) once (an upsampled source at its stored size) + output once
+        (+ the read of a read-modify-write join) + weights once"""
+        flops = 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout * desc.Ho * desc.Wo * desc.B
+        if desc.mode0 == 2:
+            flops /= 4.0   # transposed conv: 3/4 of the zero-inserted input does no algorithmic work
+        sdiv = 4 if desc.mode0 else 1
+        nbytes = elt * desc.B * (desc.Hin * desc.Win * (desc.C0 / sdiv + desc.C1) +
+                                 desc.Ho * desc.Wo * desc.Cout * (2 if desc.accumulate else 1)) + \
+            elt * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
+        return flops, nbytes
+
     def _desc(self, B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split=0, acc=0):
         return _lib.ConvDesc(B, Hin, Win, C0, C1, mode0, Ho, Wo, Cout, k, stride, pad, split, acc)
 
@@ -265,9 +295,11 @@ class UNetEngine:
         """relu: True/1 = ReLU after the residual add, 2 = ReLU on the main branch only (ResUnet decoder), 0 = none"""
         B, H, W, Cc = y.shape
         z = torch.empty_like(y) if out is None else out
+        e0 = self._pb()
         _lib.check(self.lib.dt_bn_act(_p(y), _p(ss[0]), _p(ss[1]), _p(res),
                                       _p(res_ss[0]) if res_ss else None, _p(res_ss[1]) if res_ss else None,
                                       _p(z), B * H * W, Cc, int(relu), _stream()), "dt_bn_act")
+        self._pe(e0, "bn_act_kernel", 0.0, 4.0 * y.numel() * (2 + (res is not None)))
         return z
 
     def _conv_affine_eval(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, res=None):
@@ -288,8 +320,12 @@ class UNetEngine:
                                                   _p(bnstate[2 * c.bn_off + c.cout: 2 * c.bn_off + 2 * c.cout]), BN_EPS,
                                                   c.cout, _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
         z = torch.empty((B, Hin, Win, c.cout), dtype=torch.float32, device=src0.device)
+        e0 = self._pb()
         _lib.check(self.lib.dt_conv2d_winograd_affine(C.byref(desc), _p(src0), _p(src1), _p(u), _p(z), _p(scale),
                                                       _p(shift), _p(res), _stream()), "dt_conv2d_winograd_affine")
+        if e0 is not None:
+            fl, nb = self._conv_work(desc)
+            self._pe(e0, self._wino_kernel_name(False, 5 if res is not None else 4), fl, nb + (4.0 * z.numel() if res is not None else 0.0))
         return z
 
     def _const_vec(self, value: float, n: int, device) -> torch.Tensor:
@@ -441,8 +477,10 @@ class UNetEngine:
             am8 = torch.empty((B, dh, dw), dtype=torch.uint8, device=dev)
         wh = params[hd.w_off:hd.w_off + hd.w_size]
         bh = params[hd.b_off:hd.b_off + K]
+        e0 = self._pb()
         _lib.check(lib.dt_head_fwd(_p(d), _p(wh), _p(bh), _p(logits), _p(am64), _p(am8), B, dh, dw, hd.cin, K, st),
                    "dt_head_fwd")
+        self._pe(e0, "head_fwd_kernel", 2.0 * 9 * hd.cin * K * B * dh * dw, 4.0 * B * dh * dw * (hd.cin + K))
         keep("head", x=d, H=dh, W=dw)
         if save:
             sv.d["B"] = B
@@ -792,9 +830,11 @@ class UNetEngine:
         def bn_act(y, ss, res=None, res_ss=None, y_f32=False):
             Bq, Hq, Wq, Cq = y.shape
             z = torch.empty((Bq, Hq, Wq, Cq), dtype=bf, device=dev)
+            e0 = self._pb()
             _lib.check(lib.dt_bn_act_bf16(_p(y), 1 if y_f32 else 0, _p(ss[0]), _p(ss[1]), _p(res),
                                           _p(res_ss[0]) if res_ss else None, _p(res_ss[1]) if res_ss else None, _p(z),
                                           Bq * Hq * Wq, Cq, 1, st), "dt_bn_act_bf16")
+            self._pe(e0, "bn_act_bf16_kernel", 0.0, 2.0 * y.numel() * (2 + (res is not None)))
             return z
 
         x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
@@ -882,14 +922,19 @@ class UNetEngine:
             else:
                 P = lib.dt_bn_bwd_rows_bf16(n_pix)
                 red = self._buf("bn_red", lib.dt_bn_stats_floats(P, Cq), device=dev)
+                e0 = self._pb()
                 _lib.check(lib.dt_bn_bwd_reduce_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc),
                                                      _p(ash), _p(red), n_pix, Cq, st), "dt_bn_bwd_reduce_bf16")
+                self._pe(e0, "bn_bwd_reduce_bf16_kernel", 0.0, 2.0 * y.numel() * (2 + (out_act is not None)))
             dy = torch.empty(y.shape, dtype=bf, device=dev)
+            e0 = self._pb()
             _lib.check(lib.dt_bn_bwd_apply_bf16(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd),
                                                 _p(params[c.g_off:c.g_off + Cq]), _p(asc), _p(ash), _p(red), P,
                                                 _p(grads[c.g_off:c.g_off + Cq]), _p(grads[c.b_off:c.b_off + Cq]),
                                                 _p(dy), _p(dres), 1 if dres_acc else 0, n_pix, Cq, st),
                        "dt_bn_bwd_apply_bf16")
+            self._pe(e0, "bn_bwd_apply_bf16_kernel", 0.0,
+                     2.0 * y.numel() * (3 + (out_act is not None) + (dres is not None) * (2 if dres_acc else 1)))
             return dy
 
         def wgrad(c, src0, src1, mode0, Hin, Win, dy, in_ss=None, side=True):
@@ -904,10 +949,14 @@ class UNetEngine:
             if nbytes == 0:
                 raise RuntimeError(lib.dt_last_error().decode())
             ws = self._buf("wgrad_ws", nbytes // 4, device=dev)
+            e0 = self._pb()
             _lib.check(lib.dt_conv2d_wgrad_bf16(C.byref(desc), _p(src0), _p(src1), _p(dy),
                                                 _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
                                                 _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                                 _stream()), "dt_conv2d_wgrad_bf16")
+            if e0 is not None:
+                fl, nb = self._conv_work(desc, 2)
+                self._pe(e0, "conv_wgrad_bf16_kernel (+ split-K final)", fl, nb + 2.0 * c.w_size)   # fp32 gradient out
 
         def dgrad_bn(c, dy, Hh, Ww, out0, bn_conv, y, act=None):
             """stride-1 data gradient of conv c with the BatchNorm-backward reduction of bn_conv fused (fp32 twin:
@@ -1109,9 +1158,12 @@ class UNetEngine:
         else:
             P = self.lib.dt_bn_bwd_rows(n_pix, Cc)
             red = self._buf("bn_red", self.lib.dt_bn_bwd_red_floats(n_pix, Cc), device=y.device)
+            e0 = self._pb()
             _lib.check(self.lib.dt_bn_bwd_reduce(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(asc), _p(ash),
                                                  _p(red), n_pix, Cc, st), "dt_bn_bwd_reduce")
+            self._pe(e0, "bn_bwd_reduce_kernel", 0.0, 4.0 * y.numel() * (2 + (out_act is not None)))
         dy = torch.empty_like(y)
+        e0 = self._pb()
         # eval-mode (frozen) BatchNorm: y*scale+shift with constant statistics -> dy = g*gamma*invstd, no mean terms
         fn = self.lib.dt_bn_bwd_apply if self._bwd_training else self.lib.dt_bn_bwd_apply_frozen
         _lib.check(fn(_p(dout), _p(out_act), _p(y), _p(mean), _p(invstd), _p(gamma), _p(asc),
@@ -1119,6 +1171,8 @@ class UNetEngine:
                       _p(grads[c.g_off:c.g_off + Cc]), _p(grads[c.b_off:c.b_off + Cc]),
                       _p(dy), _p(dres), 1 if dres_acc else 0, n_pix, Cc, st),
                    "dt_bn_bwd_apply")
+        # dout + y (+ stored activation) read, dy written (+ residual-branch gradient written, or read-modify-written)
+        self._pe(e0, "bn_bwd_apply_kernel", 0.0, 4.0 * y.numel() * (3 + (out_act is not None) + (dres is not None) * (2 if dres_acc else 1)))
         return dy
 
     def _wgrad(self, c: ConvSpec, grads, src0, src1, mode0, B, Hin, Win, dy, in_ss=None, side=True):
@@ -1130,6 +1184,8 @@ class UNetEngine:
         C0 = src0.shape[-1]
         C1 = 0 if src1 is None else src1.shape[-1]
         desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
+        e0 = self._pb()
+        fl, nb = self._conv_work(desc) if e0 is not None else (0.0, 0.0)
         if self.winograd and self.lib.dt_conv2d_wgrad_winograd_supported(C.byref(desc)):
             # 3x3 stride-1 layers with 64-channel blocks: the Winograd form (conv_wino_wgrad.hip, 1.6-1.75x the direct one)
             nbytes = self.lib.dt_conv2d_wgrad_winograd_workspace(C.byref(desc))
@@ -1139,6 +1195,7 @@ class UNetEngine:
                                                          _p(in_ss[0]) if in_ss else None,
                                                          _p(in_ss[1]) if in_ss else None, _stream()),
                        "dt_conv2d_wgrad_winograd")
+            self._pe(e0, "conv3x3_wino_wgrad_kernel (+ split-K reduce / final)", fl, nb)
             return
         nbytes = self.lib.dt_conv2d_wgrad_workspace(C.byref(desc))
         if nbytes == 0:
@@ -1148,6 +1205,9 @@ class UNetEngine:
                                             _p(grads[c.w_off:c.w_off + c.w_size]), _p(ws), ws.numel() * 4,
                                             _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                             _stream()), "dt_conv2d_wgrad")
+        self._pe(e0, "conv_wgrad_stem_kernel (+ reduce)" if c is self.spec.stem else
+                 ("conv_wgrad_n16_kernel (+ reduce)" if max(desc.C0 + desc.C1, desc.Cout) <= 32 and min(desc.C0 + desc.C1, desc.Cout) <= 16
+                  else "conv_wgrad_kernel (+ split-K reduce)"), fl, nb)
 
     def _dgrad_bn(self, c: ConvSpec, dy, B, H, W, out0, bn_conv: ConvSpec, y, bnws, act=None):
         """stride-1 data gradient of conv `c` into out0 with the BatchNorm-backward reduction of `bn_conv` (the layer
@@ -1327,8 +1387,10 @@ class UNetEngine:
         P = lib.dt_head_bwd_rows(B, H, W)
         red = self._buf("head_red", lib.dt_head_bwd_red_floats(B, H, W, hd.cin, K), device=dev)
         wh = params[hd.w_off:hd.w_off + hd.w_size]
+        e0 = self._pb()
         _lib.check(lib.dt_head_bwd(_p(h["x"]), _p(wh), _p(dlogits), _p(g), _p(red), B, H, W, hd.cin, K, st),
                    "dt_head_bwd")
+        self._pe(e0, "head_bwd_kernel", 4.0 * 9 * hd.cin * K * B * H * W, 4.0 * B * H * W * (2 * hd.cin + K))
         _lib.check(lib.dt_head_bwd_finalize(_p(red), P, _p(grads[hd.w_off:hd.w_off + hd.w_size]),
                                             _p(grads[hd.b_off:hd.b_off + K]), hd.cin, K, st), "dt_head_bwd_finalize")
 

@@ -691,9 +691,11 @@ class FlatAdam:
             self.sync_lr()
         n = self.p.numel()
         st = _st()
+        if skip_flag is None:          # stand-alone use: the non-finite-gradient guard of dt_clip_coef still applies
+            skip_flag = self.skip.zero_()
         _lib.check(lib.dt_sumsq(_p(grads), n, _p(self.partial), st), "dt_sumsq")
         _lib.check(lib.dt_clip_coef(_p(self.partial), self.rows, float(self.max_norm or 0.0), float(grad_scale),
-                                    _p(self.norm), _p(self.coef), st), "dt_clip_coef")
+                                    _p(self.norm), _p(self.coef), _p(skip_flag), st), "dt_clip_coef")
         b1, b2 = self.betas
         _lib.check(lib.dt_adam_advance(_p(self.t_dev), _p(skip_flag), _p(self.lr_dev), b1, b2, _p(self.hyper), st),
                    "dt_adam_advance")

@@ -88,8 +88,11 @@ class HipTrainer:
 
     # ------------------------------------------------------------------ HIP-graph replay of the whole step
     def _graph_step(self, img, mask, distmap, alpha):
+        # alpha (the per-epoch boundary ramp of segmodel.py:157-160) is baked into the captured loss blend: it belongs to
+        # the key only where it is read (BOUNDARY-RAMPED) — otherwise fit()'s ramp would re-capture the step every epoch
         key = (tuple(img.shape), img.dtype, tuple(mask.shape), mask.dtype,
-               None if distmap is None else tuple(distmap.shape), float(alpha))
+               None if distmap is None else tuple(distmap.shape),
+               float(alpha) if "BOUNDARY-RAMPED" in self.losses else None)
         g = self._graph
         if g is None or g["key"] != key:
             self._graph = g = {"key": key, "warm": 0}     # new shapes / loss blend: drop the old graph, warm up again

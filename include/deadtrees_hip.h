@@ -399,9 +399,12 @@ int dt_upsample2x_bwd_bn_bf16(const void* dup, void* dx, const dt_bn_bwd_fuse* f
 /* sum of squares of g[n] -> partial[rows]; rows = dt_sumsq_rows(n) */
 int dt_sumsq_rows(int64_t n);
 int dt_sumsq(const float* g, int64_t n, double* partial, void* stream);
-/* norm[0] = sqrt(sum partial) ; clipcoef[0] = min(1, max_norm/(norm+1e-6)) * gscale  (clip_grad_norm_) */
+/* norm[0] = sqrt(sum partial) ; clipcoef[0] = min(1, max_norm/(norm+1e-6)) * gscale  (clip_grad_norm_).
+ * skip_flag (may be NULL): set to 1 when the norm is NaN/Inf — a non-finite gradient must not reach Adam's moments even
+ * when the loss itself stayed finite (the reference's Lightning loop would have seen the NaN loss of the next step;
+ * here the update is dropped like a non-finite loss, segmodel.py:220-222).  Never cleared here. */
 int dt_clip_coef(const double* partial, int rows, float max_norm, float gscale, float* norm, float* clipcoef,
-                 void* stream);
+                 int32_t* skip_flag, void* stream);
 /* torch.optim.Adam step on a flat buffer (segmodel.py:420-425): g' = g*clipcoef[0];
  * skipped entirely when skip_flag[0] != 0 (non-finite loss: segmodel.py:220-222). */
 int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
@@ -410,8 +413,9 @@ int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* skip_flag[0] = !isfinite(loss[0])  (segmodel.py:220-222: training_step returns None) */
 int dt_skip_from_loss(const float* loss, int32_t* skip_flag, void* stream);
 /* device-resident step count: t += (skip ? 0 : 1); hyper[3] = (lr_dev[0], 1 - beta1^t, 1 - beta2^t) for
- * dt_adam_step_dev — a skipped step does not advance the bias correction (torch.optim.Adam is not called then) */
-int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_dev, float beta1, float beta2,
+ * dt_adam_step_dev — a skipped step does not advance the bias correction (torch.optim.Adam is not called then).
+ * The betas travel as doubles: torch computes 1 - beta^t in Python doubles ((double)(float)0.999 is off by 1.3e-8). */
+int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_dev, double beta1, double beta2,
                     float* hyper, void* stream);
 /* the same step with the per-step scalars on the device: hyper fp32 [3] = (lr, 1 - beta1^t, 1 - beta2^t), so a
  * training step captured in a HIP graph replays with the current learning rate and bias corrections. */

@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def parity_report(line: str) -> None:
+    """print a parity report line (flip counts, margin histograms, error ratios) AND append it to the file
+    the round keeps: $DT_PARITY_REPORT, default gpurun_out/parity_report.txt (copied to profiles/ after the GPU run)"""
+    print(line)
+    path = os.environ.get("DT_PARITY_REPORT") or os.path.join(ROOT, "gpurun_out", "parity_report.txt")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass

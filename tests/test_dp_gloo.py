@@ -234,3 +234,28 @@ def test_bf16_data_parallel_step_equals_sum_of_replica_gradients():
         p.join(60)
     assert all(r[1] for r in res), "bf16: all-reduced gradient != sum of replica gradients"
     assert all(r[2] for r in res), "bf16: replicas diverged"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_runs_as_typed():
+    """`python bench.py --gpus 2 ...` with no launcher around it: the parent spawns the two ranks as
+    a child torch.distributed.run before touching the GPU, relays rank 0's JSON line and the exit code.  DT_DIST_BACKEND
+    =gloo lets both ranks share this box's one GPU; on an 8-GPU node the same command runs RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DT_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--batch", "2", "--size", "64", "--no-cpu-baseline", "--no-legs"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 4
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["allreduce_bytes_per_step"] == 4 * 24436516
+    assert out["ms_per_step_rank_min"] <= out["ms_per_step_rank_max"]
+    assert 0 < out["roofline"]["frac"] <= 1.0 and out["roofline"]["kernels"]

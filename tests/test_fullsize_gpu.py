@@ -147,5 +147,6 @@ def test_winograd_and_direct_kernels_agree_at_full_size(batch):
     assert loss1 == pytest.approx(loss0, rel=2e-5)
     rel = float((g0 - g1).norm() / g0.norm())
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
-    print(f"[winograd vs direct, B=32 512x512] logits max diff {err / scale:.2e} of max; gradient rel-L2 {rel:.2e}, cosine {cos:.6f}")
+    from conftest import parity_report
+    parity_report(f"[winograd vs direct, B=32 512x512] logits max diff {err / scale:.2e} of max; gradient rel-L2 {rel:.2e}, cosine {cos:.6f}")
     assert rel < 5e-3 and cos > 0.99999      # measured 1.0e-3 / 1.000000; logits 9.5e-6 of max

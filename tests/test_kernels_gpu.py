@@ -317,6 +317,38 @@ def test_flat_adam_matches_torch():
     assert rel_err(pg.cpu(), ref_p.detach()) < 1e-6
 
 
+def test_flat_adam_update_size_and_nonfinite_gradient_guard():
+    """(1) the UPDATE p - p0 (3e-4 of the parameter) against torch.optim.Adam at 2e-6: catches a bias correction computed
+    from float betas ((double)(float)0.999 moves 1 - beta2^t by 1.3e-5 at t = 1); (2) a gradient with a NaN
+    and a finite loss: dt_clip_coef raises the skip flag, parameters, moments and the step count stay put."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    n = 50_001
+    p0 = 1e-3 * torch.randn(n, generator=g)   # small parameters: the fp32 grid of p (1e-10) is far below the update (3e-4)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=3e-4)
+    pg = p0.clone().to(DEV)
+    fa = ops.FlatAdam(pg, lr=3e-4, max_norm=0.0)
+    for step in range(2):
+        grad = torch.randn(n, generator=g)
+        ref_p.grad = grad.clone()
+        opt.step()
+        fa.step(grad.to(DEV))
+        upd, upd_ref = (pg.cpu() - p0).double(), (ref_p.detach() - p0).double()
+        assert float((upd - upd_ref).abs().max()) <= 2e-6 * float(upd_ref.abs().max())
+    before, m0, v0, t0 = pg.clone(), fa.m.clone(), fa.v.clone(), fa.steps_applied()
+    bad = torch.randn(n, generator=g)
+    bad[123] = float("nan")
+    skip = torch.zeros(1, dtype=torch.int32, device=DEV)
+    fa.step(bad.to(DEV), skip_flag=skip)
+    assert int(skip) == 1
+    assert torch.equal(pg, before) and torch.equal(fa.m, m0) and torch.equal(fa.v, v0) and fa.steps_applied() == t0
+    fa.step(bad.to(DEV))                       # stand-alone call (no flag given): the guard still holds
+    assert torch.equal(pg, before) and fa.steps_applied() == t0
+    fa.step(torch.randn(n, generator=g).to(DEV))
+    assert not torch.equal(pg, before) and fa.steps_applied() == t0 + 1
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 40, 64, 64), (1, 24, 40, 16, 16), (2, 20, 36, 32, 32),
                                             (2, 9, 70, 128, 96), (1, 33, 17, 64, 128)])
 def test_conv_with_fused_bn_backward_reduction(B, H, W, Cin, Cout):

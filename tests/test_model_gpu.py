@@ -97,7 +97,8 @@ def test_forward_parity_at_benchmark_tile_size_with_flip_report(mode):
     edges = [0.0, 1e-6, 1e-5, 1e-4, 1e-3, float("inf")]
     hist = [int(((margin >= lo) & (margin < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
     fmax = float(margin[flips64].max()) if bool(flips64.any()) else 0.0
-    print(f"[fp32 {mode} {B}x{H}x{W}] max |logit err| HIP {err:.2e} / torch-CPU fp32 {err_ref:.2e} (max |logit| {scale:.3f}); "
+    from conftest import parity_report
+    parity_report(f"[fp32 {mode} {B}x{H}x{W}, engine.winograd={m.engine.winograd}] max |logit err| HIP {err:.2e} / torch-CPU fp32 {err_ref:.2e} (max |logit| {scale:.3f}); "
           f"pixels {margin.numel()}, top-2 margin histogram [<1e-6, <1e-5, <1e-4, <1e-3, >=1e-3] = {hist}; "
           f"argmax flips vs fp64 oracle: {int(flips64.sum())} (largest margin among them {fmax:.2e}), "
           f"vs fp32 oracle: {int(flips32.sum())}; torch-CPU fp32 vs fp64 flips: {int((am32 != am64).sum())}")

@@ -234,6 +234,7 @@ def test_eval_mode_backward_matches_oracle(C, K):
             assert e <= 1e-4 * n + 1e-7 * gscale, (k, e / n)               # SURVEY 8(d), outright
         else:
             assert e <= max(1e-4 * n, 4.0 * e32) + 1e-7 * gscale, (k, e / n, e32 / n)
-    print(f"[eval-mode backward C={C} K={K}] worst per-tensor gradient rel-L2 vs fp64 oracle: {worst[0]:.2e} "
+    from conftest import parity_report
+    parity_report(f"[eval-mode backward C={C} K={K}, engine.winograd={m.engine.winograd}] worst per-tensor gradient rel-L2 vs fp64 oracle: {worst[0]:.2e} "
           f"({worst[1]}; torch-CPU fp32 worst {worst32:.2e}); tensors above 1e-4: {over} of {len(grads)}")
     del other

@@ -60,6 +60,42 @@ def test_nonfinite_loss_skips_update():
     assert torch.equal(m.flat_params.detach(), before)       # reference: training_step returns None -> no step
 
 
+@pytest.mark.parametrize("decoder", ["resunet", "unetplusplus", "unet"])
+def test_nan_in_a_raw_conv_output_skips_the_update(decoder, monkeypatch):
+    """a NaN that enters a raw convolution output of a block whose BatchNorm + ReLU is applied while
+    the next Winograd kernel stages it (resunet / unet++ conv2, unet with DT_MATERIALIZE_Z1=0) used to be zeroed by the
+    v_max ReLU: the loss stayed finite, the step was NOT skipped and NaN gradients reached Adam.  The NaN is injected into
+    ONE weight of a decoder conv1 (so the encoder and the input are clean): the step must be skipped, the parameters must
+    stay bit-identical, and the next clean step must train."""
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.trainer import HipTrainer
+    if decoder == "unet":
+        monkeypatch.setenv("DT_MATERIALIZE_Z1", "0")
+        monkeypatch.setenv("DT_MATERIALIZE_Z2", "0")
+    m = UNetHIP(decoder=decoder).to(DEV)
+    img, mask = synth_batch(2, 64, 64)
+    ht = HipTrainer(m)
+    ht.step(img.to(DEV), mask.to(DEV))
+    assert int(ht.last["skipped"]) == 0
+    conv1 = m.spec.decoder[1].conv1
+    clean = m.flat_params.detach().clone()
+    with torch.no_grad():
+        m.flat_params[conv1.w_off + 5] = float("nan")
+    m.engine.mark_weights_changed()
+    poisoned = m.flat_params.detach().clone()
+    ht.step(img.to(DEV), mask.to(DEV))
+    assert int(ht.last["skipped"]) == 1
+    same = (m.flat_params.detach() == poisoned) | (torch.isnan(m.flat_params.detach()) & torch.isnan(poisoned))
+    assert bool(same.all())                                   # no update, and no NaN spread through the flat buffer
+    assert int(torch.isnan(m.flat_params.detach()).sum()) == 1
+    with torch.no_grad():
+        m.flat_params.copy_(clean)
+    m.engine.mark_weights_changed()
+    ht.step(img.to(DEV), mask.to(DEV))
+    assert int(ht.last["skipped"]) == 0 and not torch.equal(m.flat_params.detach(), clean)
+
+
 def test_semsegment_steps():
     from deadtrees_amd.data.deadtreedata import DeadtreesDataModule
     from deadtrees_amd.network.segmodel import SemSegment

@@ -75,6 +75,56 @@ def test_winograd_conv_matches_fp64_and_direct_kernel(B, H, W, C0, C1, mode0, Co
     assert float((nchw(d) - got).abs().max()) <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("C1,mode0", [(0, 0), (64, 1)])
+def test_winograd_fused_input_relu_keeps_nan_like_torch(C1, mode0):
+    """the BatchNorm + ReLU applied while the Winograd kernels stage a raw producer output must behave like torch.relu /
+    bn_act on non-finite values (v_max returned the non-NaN operand, so relu(NaN) became 0 and — in a
+    source-1 chunk, whose ReLU floor is -inf — NaN became -inf): a NaN in source 0, a NaN scale and a NaN in the skip
+    source all reach the outputs they touch, in the forward kernel and in the weight gradient; padding stays zero."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C0, Cout = 2, 16, 16, 64, 64
+    x = torch.randn((B, C0, H, W), generator=g)
+    Hin, Win = (H, W) if mode0 == 0 else (2 * H, 2 * W)
+    s1 = torch.randn((B, C1, Hin, Win), generator=g) if C1 else None
+    wt = torch.randn((Cout, C0 + C1, 3, 3), generator=g) * 0.1
+    sc, sh = 1 + 0.3 * torch.randn(C0, generator=g), 0.3 * torch.randn(C0, generator=g)
+    x[0, 3, 5, 6] = float("nan")          # one raw value: relu(nan * sc + sh) = nan -> its 3x3 (6x6 up-sampled) footprint
+    if C1:
+        s1[1, 2, 9, 9] = float("nan")     # skip source: no ReLU there, but the floor select must not turn it into -inf
+    z = F.relu(x * sc[None, :, None, None] + sh[None, :, None, None])
+    if mode0 == 1:
+        z = F.interpolate(z, scale_factor=2, mode="nearest")
+    xin = torch.cat([z, s1], 1) if C1 else z
+    ref = F.conv2d(xin.double(), wt.double(), padding=1)
+    w_hwio = wt.permute(2, 3, 1, 0).contiguous().to(DEV)
+    kw = dict(src1=nhwc(s1) if C1 else None, mode0=mode0, in_scale=sc.to(DEV), in_shift=sh.to(DEV))
+    y, _, _ = ops.conv2d_winograd(nhwc(x), ops.winograd_weights(w_hwio), **kw)
+    got = nchw(y)
+    # a NaN input pixel reaches all 2x2 outputs of the Winograd tiles whose 4x4 patch holds it: a superset of the direct
+    # convolution's 3x3 footprint, at most 4x as many pixels — never an Inf, never a silent 0
+    assert bool(torch.isnan(got)[torch.isnan(ref)].all())
+    assert int(torch.isnan(got).sum()) <= 4 * int(torch.isnan(ref).sum())
+    assert not bool(torch.isinf(got).any())
+    fin = ~torch.isnan(got)
+    assert float((got[fin] - ref[fin]).abs().max()) <= 1e-5 * float(ref[fin].abs().max())
+    # weight gradient of the same layer: the NaN pixel poisons the gradient rows of ITS input channel(s) only
+    dy = torch.randn((B, Cout, Hin, Win), generator=g)
+    dw = ops.conv2d_wgrad_winograd(nhwc(x), nhwc(dy), **kw).cpu()          # HWIO
+    bad_rows = torch.zeros(C0 + C1, dtype=torch.bool)
+    bad_rows[3] = True
+    if C1:
+        bad_rows[C0 + 2] = True
+    assert bool(torch.isnan(dw[:, :, bad_rows]).all()) and not bool(torch.isnan(dw[:, :, ~bad_rows]).any())
+    assert not bool(torch.isinf(dw).any())
+    # a NaN BatchNorm coefficient (the channel's batch statistics overflowed) poisons every output pixel
+    sc2 = sc.clone()
+    sc2[7] = float("nan")
+    y2, _, _ = ops.conv2d_winograd(nhwc(torch.randn((B, C0, H, W), generator=g)), ops.winograd_weights(w_hwio),
+                                   src1=kw["src1"], mode0=mode0, in_scale=sc2.to(DEV), in_shift=sh.to(DEV))
+    assert bool(torch.isnan(y2).all())
+
+
 def test_winograd_weight_transform():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
