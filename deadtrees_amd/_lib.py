@@ -136,10 +136,10 @@ SIGNATURES = {
     "dt_sumsq_rows": (C.c_int, [I64]),
     "dt_sumsq": (C.c_int, [c_f, I64, c_f, c_f]),
     "dt_clip_coef": (C.c_int, [c_f, C.c_int, F32, F32, c_f, c_f, c_f, c_f]),
-    "dt_adam_step": (C.c_int, [c_f, c_f, c_f, c_f, I64, F32, F32, F32, F32, F32, F32, c_f, c_f, c_f]),
+    "dt_adam_step": (C.c_int, [c_f, c_f, c_f, c_f, I64, F32, F64, F64, F32, F32, F32, c_f, c_f, c_f]),
     "dt_skip_from_loss": (C.c_int, [c_f, c_f, c_f]),
     "dt_adam_advance": (C.c_int, [c_f, c_f, c_f, F64, F64, c_f, c_f]),
-    "dt_adam_step_dev": (C.c_int, [c_f, c_f, c_f, c_f, I64, c_f, F32, F32, F32, c_f, c_f, c_f]),
+    "dt_adam_step_dev": (C.c_int, [c_f, c_f, c_f, c_f, I64, c_f, F64, F64, F32, c_f, c_f, c_f]),
 }
 
 _lib = None

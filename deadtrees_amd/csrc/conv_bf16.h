@@ -22,3 +22,10 @@ struct ConvBfArgs {
 int dt_conv_bf16_dma_supported(const dt_conv_desc* d);
 int dt_conv_bf16_dma_launch(ConvBfArgs a, hipStream_t st);   // fills tiles_x / tiles_y / n_tiles / P itself
 int dt_conv_bf16_dma_stat_rows(const dt_conv_desc* d);
+
+// ---- LDS-DMA staged, double-buffered, persistent bf16 weight gradient of the 3x3 stride-1 layers with 64-channel
+// blocks and a plain (untransformed) input (conv_bf16_wgrad_dma.hip); launch -> number of split-K slabs in `ws`
+int dt_wgrad_bf16_dma_supported(const dt_conv_desc* d);
+size_t dt_wgrad_bf16_dma_workspace(const dt_conv_desc* d);
+int dt_wgrad_bf16_dma_launch(const dt_conv_desc* d, const void* src0, const void* src1, const void* dy, float* ws,
+                             hipStream_t st);

@@ -1117,6 +1117,15 @@ static int wb_cfg(const dt_conv_desc* d, int* tw, int* ksplit, int* T, int* cib,
   return DT_OK;
 }
 
+// DT_BF16_WGRAD_DMA=0 keeps every layer on the register-staged kernel below (A/B switch; read once)
+static bool wb_use_dma() {
+  static const int on = [] {
+    const char* e = getenv("DT_BF16_WGRAD_DMA");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  return on != 0;
+}
+
 static int wb_validate(const dt_conv_desc* d) {
   DT_REQUIRE(d != nullptr, "wgrad_bf16: null descriptor");
   if (d->ksize == 4) {   // the space-to-depth stem (see dt_stem_s2d_bf16)
@@ -1139,7 +1148,12 @@ extern "C" size_t dt_conv2d_wgrad_bf16_workspace(const dt_conv_desc* d) {
   int tw, ks, T, cib, cob;
   wb_cfg(d, &tw, &ks, &T, &cib, &cob);
   const size_t E = (size_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
-  return (size_t)ks * E * sizeof(float);
+  size_t need = (size_t)ks * E * sizeof(float);
+  if (wb_use_dma() && dt_wgrad_bf16_dma_supported(d)) {   // the larger of the two: in_scale decides the kernel at launch
+    const size_t n2 = dt_wgrad_bf16_dma_workspace(d);
+    if (n2 > need) need = n2;
+  }
+  return need;
 }
 
 // dw[e] = sum_p ws[p][e] in ONE launch whatever the number of split-K slabs: a workgroup owns 64 consecutive elements
@@ -1204,6 +1218,17 @@ extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, con
   DT_REQUIRE(d->C1 == 0 || src1, "wgrad_bf16: src1 missing");
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "wgrad_bf16: in_scale/in_shift must come together");
   DT_REQUIRE(workspace_bytes >= dt_conv2d_wgrad_bf16_workspace(d), "wgrad_bf16: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t E = (int64_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
+  if (in_scale == nullptr && wb_use_dma() && dt_wgrad_bf16_dma_supported(d)) {
+    // 3x3 stride-1 layers with 64-channel blocks and a stored (untransformed) input: the LDS-DMA persistent kernel
+    const int parts = dt_wgrad_bf16_dma_launch(d, src0, src1, dy, workspace, st);
+    if (parts < 0) return parts;
+    hipLaunchKernelGGL(wgrad_bf16_final_kernel, dim3((unsigned)((E / 4 + 15) / 16)), dim3(256), 0, st, workspace, dw_hwio,
+                       parts, E);
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
   WgradBfArgs a;
   int tw;
   wb_cfg(d, &tw, &a.ksplit, &a.T, &a.ci_blocks, &a.co_blocks);
@@ -1212,7 +1237,6 @@ extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, con
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.pad = d->pad;
   a.tiles_x = dt_cdiv(d->Wo, tw); a.tiles_y = dt_cdiv(d->Ho, 128 / tw);
-  hipStream_t st = (hipStream_t)stream;
   const int grid = a.ci_blocks * a.co_blocks * a.ksplit * (d->ksize == 4 ? 2 : 1);
   if (d->ksize == 4) {
     DT_REQUIRE(in_scale == nullptr, "wgrad_bf16: the stem takes no input transform");
@@ -1223,7 +1247,6 @@ extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, con
   else if (d->ksize == 3) rc = tw == 32 ? wb_launch<3, 2, 32>(a, grid, st) : wb_launch<3, 2, 16>(a, grid, st);
   else rc = tw == 32 ? wb_launch<1, 2, 32>(a, grid, st) : wb_launch<1, 2, 16>(a, grid, st);
   if (rc != DT_OK) return rc;
-  const int64_t E = (int64_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
   DT_REQUIRE((E & 3) == 0, "wgrad_bf16: weight tensor size must be a multiple of 4");
   const int64_t g = (E / 4 + 15) / 16;
   hipLaunchKernelGGL(wgrad_bf16_final_kernel, dim3((unsigned)g), dim3(256), 0, st, workspace, dw_hwio, a.ksplit, E);

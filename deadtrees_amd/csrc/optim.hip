@@ -94,7 +94,8 @@ extern "C" int dt_clip_coef(const double* partial, int rows, float max_norm, flo
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   float lr, float b1, float b2, float eps, float bc1, float bc2,
+                                                   float lr, float b1, float b2, float omb1, float omb2, float eps,
+                                                   float bc1, float bc2,
                                                    const float* __restrict__ clipcoef,
                                                    const int32_t* __restrict__ skip,
                                                    const float* __restrict__ hyper) {
@@ -117,8 +118,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       // torch.optim.Adam (single-tensor path): exp_avg.lerp_(grad, 1-b1); exp_avg_sq = b2*v + (1-b2) g^2
-      mm[k] = mm[k] + (gg[k] - mm[k]) * (1.f - b1);
-      vv[k] = vv[k] * b2 + (1.f - b2) * gg[k] * gg[k];
+      // omb = 1 - beta computed in double on the host like torch's Python scalars (1.f - 0.999f is off by 1.3e-5)
+      mm[k] = mm[k] + (gg[k] - mm[k]) * omb1;
+      vv[k] = vv[k] * b2 + omb2 * gg[k] * gg[k];
       const float denom = sqrtf(vv[k]) * rs2 + eps;
       pp[k] = pp[k] - step * (mm[k] / denom);
     }
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int64_t i = n4 << 2; i < n; ++i) {
       const float gk = g[i] * cc;
-      const float mk = m[i] + (gk - m[i]) * (1.f - b1);
-      const float vk = v[i] * b2 + (1.f - b2) * gk * gk;
+      const float mk = m[i] + (gk - m[i]) * omb1;
+      const float vk = v[i] * b2 + omb2 * gk * gk;
       m[i] = mk;
       v[i] = vk;
       p[i] = p[i] - step * (mk / (sqrtf(vk) * rs2 + eps));
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-extern "C" int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                            float beta2, float eps, float bias_c1, float bias_c2, const float* clipcoef,
+extern "C" int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, double beta1,
+                            double beta2, float eps, float bias_c1, float bias_c2, const float* clipcoef,
                             const int32_t* skip_flag, void* stream) {
   DT_REQUIRE(p && g && m && v && n > 0 && bias_c1 > 0.f && bias_c2 > 0.f, "adam: bad args");
   DT_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
@@ -147,8 +149,9 @@ extern "C" int dt_adam_step(float* p, const float* g, float* m, float* v, int64_
   int64_t grid = ((n >> 2) + 255) / 256;
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, bias_c1, bias_c2, clipcoef, skip_flag, (const float*)nullptr);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, bias_c1, bias_c2, clipcoef,
+                     skip_flag, (const float*)nullptr);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
@@ -187,7 +190,7 @@ extern "C" int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const do
 }
 
 extern "C" int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
-                                float beta1, float beta2, float eps, const float* clipcoef, const int32_t* skip_flag,
+                                double beta1, double beta2, float eps, const float* clipcoef, const int32_t* skip_flag,
                                 void* stream) {
   DT_REQUIRE(p && g && m && v && hyper && n > 0, "adam_dev: bad args");
   DT_REQUIRE(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0,
@@ -195,8 +198,9 @@ extern "C" int dt_adam_step_dev(float* p, const float* g, float* m, float* v, in
   int64_t grid = ((n >> 2) + 255) / 256;
   if (grid > 256 * 16) grid = 256 * 16;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
-                     beta2, eps, 1.f, 1.f, clipcoef, skip_flag, hyper);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f,
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, 1.f, 1.f, clipcoef, skip_flag,
+                     hyper);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

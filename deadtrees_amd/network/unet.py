@@ -89,6 +89,7 @@ class UNetEngine:
         # bf16: the input-transforming form of the LDS-DMA kernel stages its input through registers (no DMA); a stored
         # bf16 activation (2 + 2 B per element) lets conv2 and its weight gradient run the pure-DMA form: 2,235 vs 2,203
         self._mat_z1_bf16 = os.environ.get("DT_BF16_MAT_Z1", "1") != "0"
+        self._mat_dec_bf16 = os.environ.get("DT_BF16_MAT_DEC", "1") != "0"
         # when a dict: the bf16 training pass stores a copy of every intermediate tensor it produces under the
         # names of oracle/unet_bf16_ref.py (teacher-forced parity test); None in production
         self.trace: Optional[dict] = None
@@ -875,9 +876,13 @@ class UNetEngine:
         skips = [feats[3], feats[2], feats[1], feats[0], None]
         for i, blk in enumerate(sp.decoder):
             y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw, in_ss=d_ss)
-            z1 = None      # materialising here too was measured neutral (2,236 vs 2,234): the decoder keeps the fused form
+            # round 3: the activations of the 64+-channel decoder blocks are stored (bn_act, 4 B per element moved) so that
+            # conv2 / the next conv1 AND their weight gradients run the pure LDS-DMA kernels (a DMA cannot transform);
+            # with the register-staged weight gradient this was neutral (2,236 vs 2,234), DT_BF16_MAT_DEC=0 restores it
+            wide = self._mat_dec_bf16 and blk.conv2.cout % 64 == 0
+            z1 = bn_act(y1, ss1) if wide else None
             y2, h2, w2, ss2 = conv(blk.conv2, y1 if z1 is None else z1, None, 0, h1, w1, in_ss=ss1 if z1 is None else None)
-            if i == len(sp.decoder) - 1:
+            if i == len(sp.decoder) - 1 or wide:
                 z2 = bn_act(y2, ss2)
                 nxt, nxt_ss = z2, None
             else:
@@ -968,9 +973,15 @@ class UNetEngine:
             asc, ash = self._ss(bn_conv, bnws) if act is None else (None, None)
             fuse = _lib.BnBwdFuse(_p(y), _p(bnws[bn_conv.bn_off:bn_conv.bn_off + Cq]),
                                   _p(bnws[nb + bn_conv.bn_off:nb + bn_conv.bn_off + Cq]), _p(asc), _p(ash), _p(act))
-            wsel = wbdc if self._uses_dma_kernel(desc) else wbd
+            dma = self._uses_dma_kernel(desc)
+            wsel = wbdc if dma else wbd
+            e0 = self._pb()
             _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(desc), _p(dy), _p(wsel[c.w_off:c.w_off + c.w_size]), _p(out0),
                                                  _p(red), C.byref(fuse), _stream()), "dt_conv2d_bf16_bn_bwd")
+            if e0 is not None:
+                fl, nb = self._conv_work(desc, 2)
+                self._pe(e0, f"conv3x3_bf16_dma_kernel<false, {1 if act is None else 3}>" if dma else
+                         "conv_fwd_bf16_kernel (data gradient + BatchNorm-backward sums)", fl, nb + 2.0 * out0.numel())
             return red, P
 
         def dgrad(c, dy, Hin, Win, out0, out1=None, split=0, acc=False):
@@ -1031,7 +1042,7 @@ class UNetEngine:
             del dy1
             g = torch.empty(d["x"].shape, dtype=bf, device=dev)
             g_red = None
-            if i >= 1 and d["x_virtual"]:
+            if i >= 1:     # also where z2 was stored: the mask is recomputed from y2 * scale + shift either way
                 pb = sp.decoder[i - 1].conv2
                 y2p = S[f"D{i - 1}"]["y2"]
                 P = lib.dt_upsample2x_bwd_bn_bf16_rows(B, Hh // 2, Ww // 2, cx)
@@ -1440,7 +1451,7 @@ class UNetEngine:
             del dy1
             g = torch.empty_like(d["x"])
             g_red = None
-            if i >= 1 and d["x_virtual"] and self._fuse_bn:
+            if i >= 1 and self._fuse_bn:     # also where z2 was stored (DT_MATERIALIZE_Z2): the mask is recomputed from y2
                 # g is the gradient of relu(bn(y2)) of decoder block i-1 (never stored): its BatchNorm-backward
                 # reduction rides along in the pass that writes g
                 pb = sp.decoder[i - 1].conv2

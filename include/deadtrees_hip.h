@@ -407,7 +407,7 @@ int dt_clip_coef(const double* partial, int rows, float max_norm, float gscale, 
                  int32_t* skip_flag, void* stream);
 /* torch.optim.Adam step on a flat buffer (segmodel.py:420-425): g' = g*clipcoef[0];
  * skipped entirely when skip_flag[0] != 0 (non-finite loss: segmodel.py:220-222). */
-int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+int dt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, double beta1, double beta2,
                  float eps, float bias_c1, float bias_c2, const float* clipcoef, const int32_t* skip_flag,
                  void* stream);
 /* skip_flag[0] = !isfinite(loss[0])  (segmodel.py:220-222: training_step returns None) */
@@ -419,8 +419,8 @@ int dt_adam_advance(double* t_dev, const int32_t* skip_flag, const double* lr_de
                     float* hyper, void* stream);
 /* the same step with the per-step scalars on the device: hyper fp32 [3] = (lr, 1 - beta1^t, 1 - beta2^t), so a
  * training step captured in a HIP graph replays with the current learning rate and bias corrections. */
-int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
-                     float beta2, float eps, const float* clipcoef, const int32_t* skip_flag, void* stream);
+int dt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, double beta1,
+                     double beta2, float eps, const float* clipcoef, const int32_t* skip_flag, void* stream);
 
 /* ------------------------------------------------------------------ library options */
 /* Kernel-selection switches (host side, process wide; every choice computes the same values):

@@ -142,6 +142,40 @@ def test_wgrad_bf16_upsample_concat_transform(C0, C1, Cout, h, w_):
     assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
 
 
+WG_DMA_CASES = [  # B, h, w (stored size of source 0), C0, C1, mode0, Cout — the LDS-DMA persistent weight-gradient kernel
+    (2, 32, 32, 64, 0, 0, 64), (2, 37, 50, 64, 0, 0, 128), (3, 16, 16, 128, 0, 0, 64), (2, 8, 8, 64, 0, 0, 64),
+    (5, 13, 11, 64, 0, 0, 64), (1, 12, 10, 128, 64, 1, 64), (2, 8, 8, 64, 64, 1, 128), (1, 20, 44, 64, 64, 0, 64),
+    # many tiles per persistent workgroup (2,304 tiles on <= 256 workgroups), several ci / co blocks
+    (9, 64, 128, 64, 0, 0, 64), (2, 64, 64, 192, 0, 0, 128)]
+
+
+@pytest.mark.parametrize("B,h,w_,C0,C1,mode0,Cout", WG_DMA_CASES)
+def test_wgrad_bf16_dma_kernel(B, h, w_, C0, C1, mode0, Cout):
+    """conv_bf16_wgrad_dma.hip against fp64 on the same bf16-rounded operands: plain / concatenated / up-sampled inputs,
+    ragged maps (zero padding = out-of-range DMA offsets), maps of at most 16 pixels (the 8 x 16 tile form), tile ranges
+    of several tiles per workgroup; run-to-run bit-identical (no atomics)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 100 + h + C0 + Cout)
+    a = torch.randn((B, C0, h, w_), generator=g)
+    H, W = (2 * h, 2 * w_) if mode0 else (h, w_)
+    ag, a64 = bf(a)
+    xin = F.interpolate(a64, scale_factor=2, mode="nearest") if mode0 else a64
+    sg = None
+    if C1:
+        skip = torch.randn((B, C1, H, W), generator=g)
+        sg, s64 = bf(skip)
+        xin = torch.cat([xin, s64], 1)
+    wt = (torch.randn((Cout, C0 + C1, 3, 3), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(xin, wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    dyg, dy64 = bf(dy)
+    y.backward(dy64)
+    dw = ops.conv2d_wgrad_bf16(ag, dyg, 3, 1, 1, src1=sg, mode0=mode0)
+    got = dw.cpu().permute(3, 2, 0, 1).double()
+    assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
+    assert torch.equal(dw, ops.conv2d_wgrad_bf16(ag, dyg, 3, 1, 1, src1=sg, mode0=mode0))
+
+
 def test_bf16_training_step_against_fp32_path():
     """configs[2]: bf16 activations/weights, fp32 accumulate, fp32 master weights.  One step on the same batch as
     the fp32 HIP path.  Batch-statistics BatchNorm re-normalises every layer, so bf16 rounding (2^-9 of a channel's
