@@ -12,8 +12,8 @@
 //     of 128-pixel tiles (split-K over workgroups); its 8 waves = 2 (ci halves) x 2 (co halves) x 2 (pixel-row halves of
 //     the tile), 9 tap accumulators (144 registers) per wave, two waves per SIMD: one wave's DMA issue and LDS reads run
 //     beside its partner's MFMAs;
-//   * both operands go global -> LDS by DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave-instruction, no VGPRs, no
-//     ds_write); padding / ragged edges are out-of-range buffer offsets (the DMA then writes zeros);
+//   * both operands go global -> LDS by DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no ds_write);
+//     padding / ragged edges copy a 16-byte zero block instead;
 //   * two 46 KiB LDS buffers (x halo image 30 KiB + dy image 16 KiB): the DMA of tile t+1 runs under the MFMAs of tile t,
 //     ONE barrier per tile;
 //   * the images stay pixel-major (what the DMA writes) and are read with ds_read_b64_tr_b16 (hardware transpose: both
@@ -35,12 +35,15 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
 typedef void __attribute__((address_space(3)))* wd_lptr;
+typedef const void __attribute__((address_space(1)))* wd_gptr;
 typedef bf16x4w __attribute__((address_space(3)))* wd_trptr;
 
 #define WD_OOB 0x80000000u     // byte offset beyond every buffer this kernel takes (host check: operands < 2 GiB)
 #define WD_MAX_WGS 256
 #define WD_XBYTES (30 * 1024)  // x halo image: 30 pieces of 8 pixel rows x 128 B
 #define WD_BUF (46 * 1024)     // + dy image: 16 pieces
+
+__device__ __attribute__((aligned(64))) unsigned wd_zero_block[16];
 
 struct WgDmaArgs {
   const __bf16* src0;
@@ -78,15 +81,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_dma_kernel(const Wg
   const bool use0 = ci0 < a.C0;                            // the 64-channel input block lies in one source (host check)
   const int Cs = use0 ? a.C0 : a.C1, cbase = use0 ? ci0 : ci0 - a.C0, mode = use0 ? a.mode0 : 0;
   const int Hs = mode ? (a.Hin >> 1) : a.Hin, Ws = mode ? (a.Win >> 1) : a.Win;
-  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(use0 ? a.src0 : a.src1), 0,
-                                                                       use0 ? a.bytes0 : a.bytes1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dybytes, 0x00020000);
 
   // ---- DMA lane roles: lane l fills slot (l & 7) of row (l >> 3) of a piece with channel segment slot ^ 4*((row>>1)&1)
   const int l8 = lane >> 3;
   const int seg = (lane & 7) ^ (((lane >> 4) & 1) << 2);
-  const unsigned xlane_c = (unsigned)(cbase * 2 + seg * 16), ylane_c = (unsigned)(co0 * 2 + seg * 16);
-  const unsigned xpix2 = (unsigned)(Cs * 2), ypix2 = (unsigned)(a.Cout * 2);
+  const unsigned xlane_e = (unsigned)(cbase + seg * 8), ylane_e = (unsigned)(co0 + seg * 8);   // element offsets
+  const __bf16* xsrc = use0 ? a.src0 : a.src1;
+  const __bf16* zsrc = reinterpret_cast<const __bf16*>(wd_zero_block);
 
   // ---- staging context: the tile whose operands are DMA-ed next (one tile ahead of the multiplication)
   const int t_begin = split * a.tps, t_end = (t_begin + a.tps < a.T) ? t_begin + a.tps : a.T;
@@ -104,29 +105,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_dma_kernel(const Wg
     const int k = wave + 8 * i;
     if (k >= 46) return;
     unsigned char* dst = lds + buf + k * 1024;
+    const __bf16* g = zsrc;     // padding / ragged edges: every such lane copies the same 16 zero bytes
     if (k < 30) {
       const int hy = k / PPR;                                      // scalar (wave-uniform k < 30)
       const int j = k - hy * PPR;
       const int iy = s_ty * ROWS - 1 + hy;
-      const int ixc = s_tx * TW - 1 + 8 * j;                       // column of the piece's first pixel
-      const bool row_ok = (unsigned)iy < (unsigned)a.Hin;
-      const int ix = ixc + l8;
+      const int ix = s_tx * TW - 1 + 8 * j + l8;
       const int lim = (s_tx * TW + TW + 1 < a.Win) ? s_tx * TW + TW + 1 : a.Win;   // halo columns 0 .. TW + 1 only
-      const bool ok = row_ok && (unsigned)ix < (unsigned)lim;
-      const int sx = mode ? (ix >> 1) : ix;
-      const unsigned srow = (unsigned)((s_b * Hs + (mode ? (iy >> 1) : iy)) * Ws) * xpix2;
-      const unsigned off = ok ? (unsigned)sx * xpix2 + xlane_c + srow : WD_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (wd_lptr)dst, 16, off, 0, 0, 0);
+      if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)lim) {
+        const int sx = mode ? (ix >> 1) : ix;
+        const unsigned e = ((unsigned)((s_b * Hs + (mode ? (iy >> 1) : iy)) * Ws) + (unsigned)sx) * (unsigned)Cs + xlane_e;
+        g = xsrc + e;
+      }
     } else {
       const int kk = k - 30;
       const int row = kk / (TW / 8), j = kk - row * (TW / 8);
       const int oy = s_ty * ROWS + row;
       const int ox = s_tx * TW + 8 * j + l8;
-      const bool ok = oy < a.Hin && ox < a.Win;
-      const unsigned srow = (unsigned)((s_b * a.Hin + oy) * a.Win) * ypix2;
-      const unsigned off = ok ? (unsigned)ox * ypix2 + ylane_c + srow : WD_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (wd_lptr)dst, 16, off, 0, 0, 0);
+      if (oy < a.Hin && ox < a.Win) g = a.dy + ((unsigned)((s_b * a.Hin + oy) * a.Win) + (unsigned)ox) * (unsigned)a.Cout + ylane_e;
     }
+    // global_load_lds, not buffer_load ... lds: behind the buffer form hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front
+    // of the next LDS read (it cannot prove that the read misses the DMA's destination) — every piece's whole latency was
+    // exposed (first version of this kernel: 0.7x the register-staged one); the global form is not tracked that way
+    __builtin_amdgcn_global_load_lds((wd_gptr)g, (wd_lptr)dst, 16, 0, 0);
   };
   auto stage_advance = [&]() {
     if (++s_tx == a.tiles_x) {
@@ -156,17 +157,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_dma_kernel(const Wg
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  auto tr_read = [&](const unsigned char* p) -> bf16x8 {
-    const bf16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wd_trptr)p);
-    const bf16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((wd_trptr)(p + 4 * 128));
-    bf16x8 v;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      v[k] = lo[k];
-      v[4 + k] = hi[k];
-    }
-    return v;
+  // Transposed fragment reads as inline asm with explicit waits: behind a pending LDS-DMA hipcc (ROCm 7.2) puts
+  // `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 builtin (the intrinsic carries no address information, so
+  // the read "may alias" the DMA's destination): each piece's whole L2 / HBM latency was exposed right after its issue
+  // (first versions of this kernel: 0.65-0.75x the register-staged one).  The ordering that matters is established by
+  // hand instead: vmcnt(0) + barrier once per tile (below); LDS returns reads in order, so `lgkmcnt(2)` after issuing the
+  // next fragment's two reads means the current fragment has landed.
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  struct Frag { u32x2 lo, hi; };
+  const unsigned lds0 = (unsigned)(unsigned long)(wd_lptr)lds;
+  auto frag_issue = [&](Frag& fr, unsigned base, auto imm_tag) {
+    constexpr int IMM = decltype(imm_tag)::value;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(fr.lo), "=&v"(fr.hi)
+                 : "v"(base), "n"(IMM), "n"(IMM + 4 * 128)
+                 : "memory");
   };
+  auto frag_value = [&](const Frag& fr) -> bf16x8 { return __builtin_bit_cast(bf16x8, fr); };
 
   // ---- prologue: the first tile's operands
   if (t_begin < t_end) {
@@ -177,44 +184,52 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_dma_kernel(const Wg
   int step = 0;
   for (int tile = t_begin; tile < t_end; ++tile, ++step) {
     const int cur = (step & 1) * WD_BUF, nxt = WD_BUF - cur;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of this tile have landed
-    __syncthreads();                                   // ... everybody's; and nobody still reads buffer `nxt`
-    const bool more = tile + 1 < t_end;
-    const unsigned char* xa0 = lds + cur + abase0;
-    const unsigned char* xa1 = lds + cur + abase1;
-    const unsigned char* xa2 = lds + cur + abase2;
-    const unsigned char* yb = lds + cur + bbase + (wpx * WROWS * TW) * 128;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's DMA pieces of this tile have
+    const bool more = tile + 1 < t_end;                                         // landed; nobody still reads buffer `nxt`
+    // per-lane read bases of this tile: buffer + the wave's pixel half (runtime) folded in, the rest are immediates
+    const unsigned xoff = lds0 + cur + (wpx * WROWS * HWP) * 128;
+    const unsigned xa0 = xoff + abase0, xa1 = xoff + abase1, xa2 = xoff + abase2;
+    const unsigned yb = lds0 + cur + bbase + (wpx * WROWS * TW) * 128;
     // dy fragments of this wave's rows: read once per tile
-    bf16x8 fb[WROWS][XS];
-#pragma unroll
-    for (int r = 0; r < WROWS; ++r)
-#pragma unroll
-      for (int xs = 0; xs < XS; ++xs) fb[r][xs] = tr_read(yb + (r * TW + 16 * xs) * 128);
-    // x fragments: halo rows hr = 0 .. WROWS + 1 of this wave's half (halo row wpx * WROWS + hr of the tile); fragment
-    // (hr, xs, kw) serves output row r = hr - kh with tap (kh, kw) for kh = 0..2.  One fragment ahead in registers.
+    Frag fbr[WROWS][XS];
+    wd_static_for<0, WROWS * XS>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      frag_issue(fbr[i / XS][i % XS], yb, std::integral_constant<int, ((i / XS) * TW + 16 * (i % XS)) * 128>{});
+    });
+    // x fragments: halo rows hr = 0 .. WROWS + 1 of this wave's half; fragment (hr, xs, kw) serves output row r = hr - kh
+    // with tap (kh, kw) for kh = 0..2.  One fragment ahead in registers.
     constexpr int NF = (WROWS + 2) * XS * 3;
-    auto frag_addr = [&](int f) -> const unsigned char* {
-      const int kw = f % 3, xs = (f / 3) % XS, hr = f / (3 * XS);
-      const int pix = (wpx * WROWS + hr) * HWP + 16 * xs + kw;
-      const unsigned char* b = kw == 0 ? xa0 : (kw == 1 ? xa1 : xa2);
-      return b + pix * 128;
-    };
-    bf16x8 fa[2];
-    fa[0] = tr_read(frag_addr(0));
+    Frag far[2];
+    frag_issue(far[0], xa0, std::integral_constant<int, 0>{});
+    bf16x8 fb[WROWS][XS];
     wd_static_for<0, NF>([&](auto fc) {
       constexpr int f = decltype(fc)::value;
       constexpr int kw = f % 3, xs = (f / 3) % XS, hr = f / (3 * XS);
-      if constexpr (f + 1 < NF) fa[(f + 1) & 1] = tr_read(frag_addr(f + 1));
+      if constexpr (f + 1 < NF) {
+        constexpr int f1 = f + 1, kw1 = f1 % 3, xs1 = (f1 / 3) % XS, hr1 = f1 / (3 * XS);
+        frag_issue(far[f1 & 1], kw1 == 0 ? xa0 : (kw1 == 1 ? xa1 : xa2),
+                   std::integral_constant<int, (hr1 * HWP + 16 * xs1 + kw1) * 128>{});
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if constexpr (f == 0) {   // everything older than the two reads just issued has landed: the dy fragments too
+#pragma unroll
+        for (int r = 0; r < WROWS; ++r)
+#pragma unroll
+          for (int x2 = 0; x2 < XS; ++x2) fb[r][x2] = frag_value(fbr[r][x2]);
+      }
+      const bf16x8 av = frag_value(far[f & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int r = hr - kh;
         if (r >= 0 && r < WROWS)
-          acc[3 * kh + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f & 1], fb[r][xs], acc[3 * kh + kw], 0, 0, 0);
+          acc[3 * kh + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, fb[r][xs], acc[3 * kh + kw], 0, 0, 0);
       }
-      // the next tile's DMA pieces, one every few fragments, beside the matrix work
-      if constexpr ((f % (NF / 6)) == 1 && f / (NF / 6) < 6) {
-        if (more) stage_piece(f / (NF / 6), nxt);
+      // the next tile's DMA pieces go out with the first six fragments (a piece needs no registers)
+      if constexpr (f < 6) {
+        if (more) stage_piece(f, nxt);
       }
       __builtin_amdgcn_sched_barrier(0);
     });

@@ -71,7 +71,9 @@ class UNetEngine:
         # BatchNorm-backward reduction of a block-output layer inside the fp32 gradient-JOIN epilogue: measured slower
         # than the separate pass (526 vs 530 tiles/s, same box: 48 extra loads per lane in the read-modify-write
         # epilogue); the bf16 path keeps it (its join epilogue is LDS-staged, +0.5 %).  Kernel support stays tested.
-        self.fuse_join_fp32 = bool(os.environ.get("DT_FUSE_JOIN_FP32"))
+        # Round 3, Winograd engine: the join epilogue form 3 of conv3x3_wino_kernel carries the sums at +0.7 % of the step
+        # (763.9 vs 758.8 tiles/s, same box) and removes 13 of the 23 remaining bn_bwd_reduce passes: on with Winograd.
+        self.fuse_join_fp32 = os.environ.get("DT_FUSE_JOIN_FP32", "1" if os.environ.get("DT_FP32_WINOGRAD", "1") != "0" else "0") != "0"
         self._fuse_bn = not os.environ.get("DT_NO_BN_FUSE")   # A/B switch for the plain fused reductions
         # fp32 3x3 stride-1 layers (forward + data gradient) on the Winograd F(2x2,3x3) kernel where its shape conditions
         # hold (conv_wino.hip: 1.6-2.0x the direct kernel per layer); DT_FP32_WINOGRAD=0 keeps the exact-fma direct kernel
@@ -960,8 +962,8 @@ class UNetEngine:
                                                 _p(in_ss[0]) if in_ss else None, _p(in_ss[1]) if in_ss else None,
                                                 _stream()), "dt_conv2d_wgrad_bf16")
             if e0 is not None:
-                fl, nb = self._conv_work(desc, 2)
-                self._pe(e0, "conv_wgrad_bf16_kernel (+ split-K final)", fl, nb + 2.0 * c.w_size)   # fp32 gradient out
+                fl, wbytes = self._conv_work(desc, 2)
+                self._pe(e0, "conv_wgrad_bf16_kernel (+ split-K final)", fl, wbytes + 2.0 * c.w_size)   # fp32 gradient out
 
         def dgrad_bn(c, dy, Hh, Ww, out0, bn_conv, y, act=None):
             """stride-1 data gradient of conv c with the BatchNorm-backward reduction of bn_conv fused (fp32 twin:
@@ -979,9 +981,9 @@ class UNetEngine:
             _lib.check(lib.dt_conv2d_bf16_bn_bwd(C.byref(desc), _p(dy), _p(wsel[c.w_off:c.w_off + c.w_size]), _p(out0),
                                                  _p(red), C.byref(fuse), _stream()), "dt_conv2d_bf16_bn_bwd")
             if e0 is not None:
-                fl, nb = self._conv_work(desc, 2)
+                fl, wbytes = self._conv_work(desc, 2)
                 self._pe(e0, f"conv3x3_bf16_dma_kernel<false, {1 if act is None else 3}>" if dma else
-                         "conv_fwd_bf16_kernel (data gradient + BatchNorm-backward sums)", fl, nb + 2.0 * out0.numel())
+                         "conv_fwd_bf16_kernel (data gradient + BatchNorm-backward sums)", fl, wbytes + 2.0 * out0.numel())
             return red, P
 
         def dgrad(c, dy, Hin, Win, out0, out1=None, split=0, acc=False):
