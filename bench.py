@@ -196,6 +196,9 @@ def kernel_family(name: str):
         return ("bf16 LDS-DMA convolution forward / data gradient", "mfma", 1.0, mf, "TFLOP/s")
     if name.startswith("conv_wgrad_bf16"):
         return ("bf16 weight gradient + split-K final", "mfma", 1.0, mf, "TFLOP/s")
+    if name.startswith("conv3x3_bf16_narrow"):   # HBM-bound by a wide margin (64-96 B and 4.6-18 kFLOP per pixel)
+        return ("bf16 narrow-layer convolution forward / data gradient (Cin, Cout <= 32 at full resolution)", "hbm", 0.0,
+                PEAK_HBM_GBS, "GB/s")
     if name.startswith("conv_fwd_bf16"):
         return ("bf16 register-staged convolution (Cout <= 32, stride 2, 1x1, stem)", "mfma", 1.0, mf, "TFLOP/s")
     if name.startswith("conv_wgrad"):
@@ -384,7 +387,14 @@ def train_leg(args, ctx, precision, B, headline):
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                roof["traffic"] = json.load(open(tfile)).get(name, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                # rocprofv3 spells every template argument (conv3x3_wino_kernel<false, 0, false>); the engine's name for
+                # the launch leaves defaulted ones out: exact key first, then the key this name is a prefix of
+                ent = tj.get(name) or next((v for k, v in sorted(tj.items()) if k.startswith(name[:-1] + ",") and isinstance(v, dict)), {})
+                roof["traffic"] = ent.get("hbm_bytes_per_launch")
+                if ent:
+                    roof["traffic_detail"] = {k: ent[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch", "read_shape",
+                                                                   "read_factor", "write_shape", "write_factor") if k in ent}
             except Exception:
                 pass
         roof["kernels"] = kernels
@@ -459,8 +469,8 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
         src = u8 if src is None else src
         if use_graph:
             return graphed(src)
-        x = ops.normalize_u8(src, MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
-        return model.predict_classes(x, dtype="uint8", precision=args.precision)
+        x = ops.normalize_u8(src, MEAN, STD, 3)          # NHWC fp32: the kernels' layout, no NCHW round trip
+        return model.predict_classes(x, dtype="uint8", precision=args.precision, nhwc=True)
 
     for _ in range(args.warmup):
         step()
@@ -516,8 +526,12 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
 
         class _U8:
             def run_u8(self, tiles_u8, device=None):
-                x = ops.normalize_u8(tiles_u8.to(dev, non_blocking=True), MEAN, STD, 3).permute(0, 3, 1, 2).contiguous()
-                return model.predict_classes(x, dtype="uint8", precision=args.precision)
+                x = ops.normalize_u8(tiles_u8.to(dev, non_blocking=True), MEAN, STD, 3)
+                return model.predict_classes(x, dtype="uint8", precision=args.precision, nhwc=True)
+
+            def run_blocks(self, raster, d, first, count):      # PyTorchInference.run_blocks on the bench's model
+                x = ops.split_normalize_u8(raster, d, first, count, MEAN, STD, 3)
+                return model.predict_classes(x, dtype="uint8", precision=args.precision, nhwc=True)
 
         ortho = np.random.default_rng(7 + rank).integers(0, 256, (4, 2048, 2048), dtype=np.uint8)
         infer_tile(_U8(), ortho, subtile=S, batch_size=64, device=str(dev))          # warm-up

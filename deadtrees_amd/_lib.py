@@ -82,6 +82,9 @@ SIGNATURES = {
     "dt_nchw_to_nhwc": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_nhwc_to_nchw": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_normalize_u8": (C.c_int, [c_f, c_f, I64, C.c_int, C.c_int, C.POINTER(F32), C.POINTER(F32), c_f]),
+    "dt_split_normalize_u8": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(F32), C.POINTER(F32), c_f]),
+    "dt_band_has_data": (C.c_int, [c_f, I64, c_f, c_f]),
     "dt_head_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_head_bwd_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dt_head_bwd_red_floats": (I64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

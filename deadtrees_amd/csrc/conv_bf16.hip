@@ -443,6 +443,10 @@ static void bf_cfg(const dt_conv_desc* d, int* tw_, int* tn_, int* ck_, int* mt_
     *tw_ = 32; *tn_ = 64; *ck_ = 16; *mt_ = 2;
     return;
   }
+  if (dt_conv_bf16_narrow_supported(d)) {   // conv_bf16_narrow.hip: Cin, Cout in {16, 32} at full resolution (mt = 16)
+    *tw_ = 32; *tn_ = 16; *ck_ = 16; *mt_ = 16;
+    return;
+  }
   if (dt_conv_bf16_dma_supported(d)) {   // conv_bf16_dma.hip: 512-pixel x 64-channel tiles, 8 waves (reported as mt = 8)
     *tw_ = 32; *tn_ = 64; *ck_ = 32; *mt_ = 8;
     return;
@@ -481,6 +485,7 @@ extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
   int tw, tn, ck, mt;
   bf_cfg(d, &tw, &tn, &ck, &mt);
   if (mt == 8) return dt_conv_bf16_dma_stat_rows(d);
+  if (mt == 16) return dt_conv_bf16_narrow_grid(d);
   return d->B * dt_cdiv(d->Ho, 128 * mt / tw) * dt_cdiv(d->Wo, tw);
 }
 
@@ -531,6 +536,7 @@ static int conv2d_bf16_impl(const dt_conv_desc* d, const void* src0, const void*
   a.P = d->B * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
   if (mt == 8) return dt_conv_bf16_dma_launch(a, st);
+  if (mt == 16) return dt_conv_bf16_narrow_launch(d, a, st);   // (accumulate == 0 there: no stored-activation joins)
   if (d->ksize == 4) {
     DT_REQUIRE(in_scale == nullptr && fuse == nullptr, "conv_bf16: the stem takes no input transform / fused reduction");
     return bf_launch<4, 1, 32, 64, 16, 2>(a, st);

@@ -861,6 +861,66 @@ extern "C" int dt_normalize_u8(const uint8_t* src, float* dst, int64_t n_pix, in
   return DT_OK;
 }
 
+// ------------------------------------------------------------------ tiled inference input
+// deployment/tiler.py:121-134 + utils/data_handling.py:9-20 (zero-pad the raster to the tile, cut it into d x d blocks in
+// row-major block order) + scripts/inference.py:94-96 (albumentations Normalize per sub-tile) as ONE gather: raster uint8
+// [Cs][h][w] (band-major, what rioxarray hands over) -> fp32 NHWC sub-tiles [count][d][d][Cd], blocks first .. first +
+// count - 1 of the nbx-wide block grid.  Pixels beyond the raster are the tiler's zero padding, normalised like any
+// other zero byte.  One thread per output pixel: Cd byte loads (coalesced along x per band), Cd dword stores.
+__global__ __launch_bounds__(256) void split_normalize_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                                 int h, int w, int d, int nbx, int first, int64_t n_pix,
+                                                                 int Cd, f32x4 mean, f32x4 stdv) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t plane = (int64_t)h * w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    const int x = (int)(i % d), y = (int)((i / d) % d), blk = first + (int)(i / ((int64_t)d * d));
+    const int gy = (blk / nbx) * d + y, gx = (blk % nbx) * d + x;
+    const bool in = gy < h && gx < w;
+    for (int c = 0; c < Cd; ++c) {
+      const float v = in ? (float)src[c * plane + (int64_t)gy * w + gx] : 0.f;
+      dst[i * Cd + c] = (v - mean[c] * 255.f) * (1.f / (stdv[c] * 255.f));   // the arithmetic of normalize_u8_kernel
+    }
+  }
+}
+
+extern "C" int dt_split_normalize_u8(const uint8_t* raster_chw, float* dst_nhwc, int Csrc, int h, int w, int d, int nbx,
+                                     int first_block, int n_blocks, int Cdst, const float* mean, const float* stdv,
+                                     void* stream) {
+  DT_REQUIRE(raster_chw && dst_nhwc && mean && stdv && h > 0 && w > 0 && d > 0 && nbx > 0 && first_block >= 0 &&
+                 n_blocks > 0 && Cdst > 0 && Cdst <= 4 && Cdst <= Csrc,
+             "split_normalize_u8: bad args");
+  f32x4 m = {0, 0, 0, 0}, s = {1, 1, 1, 1};
+  for (int c = 0; c < Cdst; ++c) {
+    m[c] = mean[c];
+    s[c] = stdv[c];
+  }
+  const int64_t n_pix = (int64_t)n_blocks * d * d;
+  hipLaunchKernelGGL(split_normalize_u8_kernel, dim3(ew_grid(n_pix)), dim3(256), 0, (hipStream_t)stream, raster_chw,
+                     dst_nhwc, h, w, d, nbx, first_block, n_pix, Cdst, m, s);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// scripts/inference.py:60-62 `is_valid_tile`: a raster whose first band holds only 0 / 255 is skipped.  flag[0] (int32,
+// zeroed by the caller) becomes 1 as soon as any byte differs from both: a reduction without a host pass over the raster.
+__global__ __launch_bounds__(256) void band_has_data_kernel(const uint8_t* __restrict__ band, int64_t n,
+                                                            int32_t* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool any = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint8_t v = band[i];
+    any = any || (v != 0 && v != 255);
+  }
+  if (__builtin_amdgcn_ballot_w64(any) != 0 && (threadIdx.x & 63) == 0) flag[0] = 1;   // idempotent store: no atomic
+}
+
+extern "C" int dt_band_has_data(const uint8_t* band, int64_t n, int32_t* flag, void* stream) {
+  DT_REQUIRE(band && flag && n > 0, "band_has_data: bad args");
+  hipLaunchKernelGGL(band_has_data_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, band, n, flag);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ training augmentation on the device
 // data/deadtreedata.py:128-146 `train_transform`: OneOf(HorizontalFlip, VerticalFlip) -> RandomRotate90 ->
 // RandomBrightnessContrast(brightness_by_max=False) -> Normalize -> ToTensorV2, per sample on loader CPUs.

@@ -67,9 +67,21 @@ class PyTorchInference(Inference):
         """uint8 [B,H,W,4] (what the tiler cuts) -> uint8 class map [B,H,W]; normalisation on the device
         (reference: per-tile albumentations Normalize on the CPU, scripts/inference.py:94-96)."""
         self._model.to(device)
-        x = ops.normalize_u8(tiles_u8_nhwc.to(device), MEAN, STD, self._channels)   # NHWC f32
-        x = x.permute(0, 3, 1, 2).contiguous()
-        return self._model.predict_classes(x, dtype="uint8")
+        x = ops.normalize_u8(tiles_u8_nhwc.to(device), MEAN, STD, self._channels)   # NHWC f32: the kernels' layout
+        return self._model.predict_classes(x, dtype="uint8", nhwc=True)
+
+    def run_blocks(self, raster_chw_u8: torch.Tensor, d: int, first: int, count: int) -> torch.Tensor:
+        """sub-tiles ``first`` .. ``first + count - 1`` of a band-major uint8 raster that already lives on the device ->
+        uint8 class maps [count,d,d]: block split + zero padding + Normalize + channel selection are ONE gather
+        (``dt_split_normalize_u8``) straight into the stem's NHWC input"""
+        self._model.to(raster_chw_u8.device)
+        x = ops.split_normalize_u8(raster_chw_u8, d, first, count, MEAN, STD, self._channels)
+        return self._model.predict_classes(x, dtype="uint8", nhwc=True)
+
+    @staticmethod
+    def is_valid_raster(raster_chw_u8: torch.Tensor) -> bool:
+        """scripts/inference.py:60-62 ``is_valid_tile`` on a raster in HBM: False when band 1 holds only 0 / 255"""
+        return bool(int(ops.band_has_data(raster_chw_u8[0])) != 0)
 
 
 class PyTorchEnsembleInference:
@@ -119,8 +131,8 @@ class GraphedTilePredictor:
         self._graphs = {}
 
     def _eager(self, tiles_u8):
-        x = ops.normalize_u8(tiles_u8, MEAN, STD, self.c).permute(0, 3, 1, 2).contiguous()
-        return self.model.predict_classes(x, dtype="uint8", precision=self.precision)
+        x = ops.normalize_u8(tiles_u8, MEAN, STD, self.c)
+        return self.model.predict_classes(x, dtype="uint8", precision=self.precision, nhwc=True)
 
     def __call__(self, tiles_u8: torch.Tensor) -> torch.Tensor:
         key = (tuple(tiles_u8.shape), tiles_u8.device)

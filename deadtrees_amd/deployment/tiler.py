@@ -229,12 +229,16 @@ def _infer_tile_on_device(inference, arr_chw_u8: np.ndarray, subtile: int, batch
         raise ValueError(f"Shapes unaligned: {tuple(tile_shape)} / {d}")
     nby, nbx = -(-h // d), -(-w // d)
     x = torch.from_numpy(np.ascontiguousarray(arr_chw_u8)).to(device, non_blocking=True)
-    if (nby * d, nbx * d) != (h, w):
-        xp = torch.zeros((C, nby * d, nbx * d), dtype=torch.uint8, device=x.device)
-        xp[:, :h, :w] = x
-        x = xp
-    blocks = x.view(C, nby, d, nbx, d).permute(1, 3, 2, 4, 0).contiguous().view(nby * nbx, d, d, C)
-    outs = [inference.run_u8(blocks[j:j + batch_size], device=device) for j in range(0, nby * nbx, batch_size)]
+    if hasattr(inference, "run_blocks"):
+        # round 3: split + zero padding + Normalize + NHWC in one gather per batch (dt_split_normalize_u8), no ATen passes
+        outs = [inference.run_blocks(x, d, j, min(batch_size, nby * nbx - j)) for j in range(0, nby * nbx, batch_size)]
+    else:
+        if (nby * d, nbx * d) != (h, w):
+            xp = torch.zeros((C, nby * d, nbx * d), dtype=torch.uint8, device=x.device)
+            xp[:, :h, :w] = x
+            x = xp
+        blocks = x.view(C, nby, d, nbx, d).permute(1, 3, 2, 4, 0).contiguous().view(nby * nbx, d, d, C)
+        outs = [inference.run_u8(blocks[j:j + batch_size], device=device) for j in range(0, nby * nbx, batch_size)]
     maps = torch.cat(outs, dim=0).to(torch.uint8)
     merged = maps.view(nby, nbx, d, d).permute(0, 2, 1, 3).reshape(nby * d, nbx * d)
     return merged[:h, :w].contiguous().cpu().numpy()

@@ -341,11 +341,18 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x_nchw: torch.Tensor, params: torch.Tensor, bnstate: torch.Tensor, training: bool,
-                save: bool, want_argmax: Optional[str] = None):
+                save: bool, want_argmax: Optional[str] = None, nhwc: bool = False):
+        """nhwc=True: the input already is the kernels' layout [B,H,W,C] (the tiled-inference gather produces it):
+        no NCHW -> NHWC pass"""
         sp = self.spec
-        if x_nchw.dim() != 4 or x_nchw.shape[1] != sp.in_channels:
-            raise RuntimeError(f"expected input [B,{sp.in_channels},H,W], got {tuple(x_nchw.shape)}")
-        B, Cin, H, W = x_nchw.shape
+        if nhwc:
+            if x_nchw.dim() != 4 or x_nchw.shape[3] != sp.in_channels:
+                raise RuntimeError(f"expected NHWC input [B,H,W,{sp.in_channels}], got {tuple(x_nchw.shape)}")
+            B, H, W, Cin = x_nchw.shape
+        else:
+            if x_nchw.dim() != 4 or x_nchw.shape[1] != sp.in_channels:
+                raise RuntimeError(f"expected input [B,{sp.in_channels},H,W], got {tuple(x_nchw.shape)}")
+            B, Cin, H, W = x_nchw.shape
         if H % 32 or W % 32:
             raise RuntimeError(f"H and W must be divisible by 32 (encoder depth 5), got {H}x{W}")
         if x_nchw.dtype != torch.float32 or not x_nchw.is_cuda:
@@ -372,8 +379,11 @@ class UNetEngine:
             bnws = torch.empty(4 * sp.n_bn_channels, dtype=torch.float32, device=dev)
             sv.d["bnws"] = bnws
 
-        x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
-        _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
+        if nhwc:
+            x = x_nchw
+        else:
+            x = torch.empty((B, H, W, Cin), dtype=torch.float32, device=dev)
+            _lib.check(lib.dt_nchw_to_nhwc(_p(x_nchw), _p(x), B, Cin, H, W, st), "dt_nchw_to_nhwc")
 
         def keep(key, **kw):
             if save:
@@ -593,12 +603,17 @@ class UNetEngine:
         self._ws[name + "_key"], self._ws[name] = key, buf
         return buf
 
-    def _uses_dma_kernel(self, desc) -> bool:
-        """the LDS-DMA staged kernels (reported as mt == 8) read the CHUNKED weight images"""
+    def _bf16_mt(self, desc) -> int:
+        """kernel family dt_conv2d_bf16 picks for `desc`: 8 = LDS-DMA staged (conv_bf16_dma.hip), 16 = lean narrow-layer
+        kernel (conv_bf16_narrow.hip), else the register-staged kernels' tile multiplier"""
         tw, tn, ck, mt = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         if self.lib.dt_conv2d_bf16_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck), C.byref(mt)) != 0:
-            return False
-        return mt.value == 8
+            return -1
+        return mt.value
+
+    def _uses_dma_kernel(self, desc) -> bool:
+        """the LDS-DMA staged kernels (reported as mt == 8) read the CHUNKED weight images"""
+        return self._bf16_mt(desc) == 8
 
     def _conv_bf16(self, desc, src0, src1, w, out0, out1, stats, in_ss, what="dt_conv2d_bf16", w_chunked=None):
         if w_chunked is not None and self._uses_dma_kernel(desc):
@@ -626,6 +641,9 @@ class UNetEngine:
                 2.0 * desc.ksize ** 2 * (desc.C0 + desc.C1) * desc.Cout
             if mt.value == 8:     # the LDS-DMA staged 512-pixel kernel (conv_bf16_dma.hip)
                 name = f"conv3x3_bf16_dma_kernel<{'true' if in_ss else 'false'}, {2 if desc.accumulate else 0}>"
+            elif mt.value == 16:  # the lean narrow-layer kernel (conv_bf16_narrow.hip)
+                name = (f"conv3x3_bf16_narrow_kernel<{desc.C0 // 16}, {desc.Cout // 16}, "
+                        f"{'true' if in_ss else 'false'}, false>")
             else:
                 name = (f"conv_fwd_bf16_kernel<{desc.ksize}, {desc.stride}, {tw.value}, {tn.value}, {ck.value}, "
                         f"{mt.value}, {'true' if in_ss else 'false'}>")
@@ -982,8 +1000,10 @@ class UNetEngine:
                                                  _p(red), C.byref(fuse), _stream()), "dt_conv2d_bf16_bn_bwd")
             if e0 is not None:
                 fl, wbytes = self._conv_work(desc, 2)
+                narrow = self._bf16_mt(desc) == 16
                 self._pe(e0, f"conv3x3_bf16_dma_kernel<false, {1 if act is None else 3}>" if dma else
-                         "conv_fwd_bf16_kernel (data gradient + BatchNorm-backward sums)", fl, wbytes + 2.0 * out0.numel())
+                         (f"conv3x3_bf16_narrow_kernel<{desc.C0 // 16}, {desc.Cout // 16}, false, true>" if narrow else
+                          "conv_fwd_bf16_kernel (data gradient + BatchNorm-backward sums)"), fl, wbytes + 2.0 * out0.numel())
             return red, P
 
         def dgrad(c, dy, Hin, Win, out0, out1=None, split=0, acc=False):
@@ -1773,12 +1793,14 @@ class UNetHIP(nn.Module):
         return logits
 
     @torch.no_grad()
-    def predict_classes(self, x: torch.Tensor, dtype: str = "int64", precision: str = "fp32") -> torch.Tensor:
+    def predict_classes(self, x: torch.Tensor, dtype: str = "int64", precision: str = "fp32", nhwc: bool = False) -> torch.Tensor:
         """forward + argmax fused in the head kernel (deployment/inference.py:60-62), eval-mode BN.
         precision "bf16": bf16 activations/weights with fp32 accumulation (the AMP setting of the reference's
         training protocol) — class maps agree with fp32 wherever the logit margin exceeds bf16 rounding."""
         self._require_gpu(x)
         if precision == "bf16":
+            if nhwc:
+                x = x.permute(0, 3, 1, 2).contiguous()
             _, am = self.engine.forward_bf16_eval(x.float(), self.flat_params.detach(), self.bn_state, want_argmax=dtype)
             return am
         if precision != "fp32":
@@ -1787,7 +1809,7 @@ class UNetHIP(nn.Module):
         self.eval()
         try:
             _, am = self.engine.forward(x.float(), self.flat_params.detach(), self.bn_state, False, save=False,
-                                        want_argmax=dtype)
+                                        want_argmax=dtype, nhwc=nhwc)
         finally:
             self.train(was)
         return am

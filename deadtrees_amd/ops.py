@@ -571,6 +571,35 @@ def upsample2x_bwd_bf16(dup):
     return dx
 
 
+def split_normalize_u8(raster_chw_u8, d: int, first: int, count: int, mean, std, c_dst: int):
+    """band-major uint8 raster [C,h,w] on the device -> the fp32 NHWC sub-tiles [count,d,d,c_dst] ``first`` .. of the
+    row-major d x d block grid of the zero-padded raster (tiler.py:121-134 + make_blocks_vectorized + Normalize, fused)"""
+    _gpu(raster_chw_u8)
+    if raster_chw_u8.dtype != torch.uint8 or raster_chw_u8.dim() != 3:
+        raise RuntimeError("split_normalize_u8: raster must be uint8 [C,h,w]")
+    cs, h, w = raster_chw_u8.shape
+    nbx = -(-w // d)
+    nby = -(-h // d)
+    if first < 0 or count <= 0 or first + count > nbx * nby:
+        raise RuntimeError(f"split_normalize_u8: blocks {first}..{first + count - 1} outside the {nby} x {nbx} grid")
+    out = torch.empty((count, d, d, c_dst), dtype=torch.float32, device=raster_chw_u8.device)
+    m = (C.c_float * c_dst)(*[float(v) for v in mean[:c_dst]])
+    s = (C.c_float * c_dst)(*[float(v) for v in std[:c_dst]])
+    _lib.check(_lib.load().dt_split_normalize_u8(_p(raster_chw_u8.contiguous()), _p(out), cs, h, w, d, nbx, first, count,
+                                                 c_dst, m, s, _st()), "dt_split_normalize_u8")
+    return out
+
+
+def band_has_data(band_u8) -> torch.Tensor:
+    """int32[1] device flag: 1 iff some byte is neither 0 nor 255 (scripts/inference.py:60-62 is_valid_tile, no host pass)"""
+    _gpu(band_u8)
+    if band_u8.dtype != torch.uint8:
+        raise RuntimeError("band_has_data: uint8 band expected")
+    flag = torch.zeros(1, dtype=torch.int32, device=band_u8.device)
+    _lib.check(_lib.load().dt_band_has_data(_p(band_u8.contiguous()), band_u8.numel(), _p(flag), _st()), "dt_band_has_data")
+    return flag
+
+
 def augment_normalize_u8(src_u8_nhwc, geo, bc, mean, std, c_dst):
     """uint8 [B,H,W,Csrc] -> fp32 [B,H,W,c_dst]: flip / rot90 / brightness-contrast LUT / normalise in one pass
     (data/deadtreedata.py:128-146).  geo int32 [B,2] = (flip, rot k), bc fp32 [B,2] = (alpha, beta)."""

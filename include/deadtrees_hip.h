@@ -187,6 +187,15 @@ int dt_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, vo
 /* mean/std are HOST arrays of Cdst floats (passed by value to the kernel). */
 int dt_normalize_u8(const uint8_t* src, float* dst, int64_t n_pix, int Csrc, int Cdst, const float* mean,
                     const float* std, void* stream);
+/* Tiled-inference input in one gather (reference deployment/tiler.py:121-134 zero-pad + utils/data_handling.py:9-20
+ * make_blocks_vectorized + scripts/inference.py:94-96 per-tile Normalize): band-major uint8 raster [Csrc][h][w] ->
+ * fp32 NHWC sub-tiles [n_blocks][d][d][Cdst] for the blocks first_block .. of the row-major block grid that is nbx blocks
+ * wide; pixels beyond the raster are the tiler's zero padding (normalised like a zero byte). */
+int dt_split_normalize_u8(const uint8_t* raster_chw, float* dst_nhwc, int Csrc, int h, int w, int d, int nbx,
+                          int first_block, int n_blocks, int Cdst, const float* mean, const float* stdv, void* stream);
+/* scripts/inference.py:60-62 is_valid_tile: flag[0] (int32, zero it first) = 1 iff some byte of band[n] is neither 0 nor
+ * 255 (a raster whose first band is all 0 / 255 is skipped by the reference's driver). */
+int dt_band_has_data(const uint8_t* band, int64_t n, int32_t* flag, void* stream);
 
 /* Training augmentation on the device, data/deadtreedata.py:128-146 `train_transform`:
  * OneOf(HorizontalFlip, VerticalFlip), RandomRotate90, RandomBrightnessContrast(brightness_by_max=False),

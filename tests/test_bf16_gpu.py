@@ -34,7 +34,11 @@ CASES = [(2, 32, 32, 64, 64, 3, 1, 1), (1, 40, 24, 16, 16, 3, 1, 1), (2, 16, 16,
          (2, 8, 8, 32, 48, 3, 1, 1), (2, 32, 32, 64, 128, 3, 2, 1), (2, 32, 32, 64, 128, 1, 2, 0),
          (1, 34, 70, 512, 64, 3, 1, 1),
          # 512-pixel workgroup tiles (Cout >= 128 and >= 1024 tiles): ragged bottom edge, 2 n-tiles, Cin = 16 (mod 32)
-         (16, 120, 128, 48, 128, 3, 1, 1)]
+         (16, 120, 128, 48, 128, 3, 1, 1),
+         # the lean narrow-layer kernel (conv_bf16_narrow.hip: Cin, Cout in {16, 32}, maps >= 8 x 32): every channel
+         # combination, ragged edges, several tiles per persistent workgroup (4 x 128 x 128 -> 256 tiles; 9 x 256 x 256)
+         (2, 40, 64, 16, 16, 3, 1, 1), (2, 37, 70, 32, 16, 3, 1, 1), (3, 64, 64, 32, 32, 3, 1, 1),
+         (2, 16, 32, 16, 32, 3, 1, 1), (4, 128, 128, 16, 16, 3, 1, 1), (9, 256, 256, 32, 16, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
@@ -79,6 +83,33 @@ def test_conv_bf16_upsample_concat_transform_split_accumulate(B, h, w_, Cout):
                                 split=64, out0=base.clone(), accumulate=True)
     close_bf16(to_nchw(o0), ref[:, :64] + to_nchw(base))
     close_bf16(to_nchw(o1), ref[:, 64:])
+
+
+@pytest.mark.parametrize("C0,Cout,h,w_", [(32, 16, 20, 24), (16, 16, 8, 16), (32, 32, 33, 17), (16, 32, 16, 16)])
+def test_conv_bf16_narrow_kernel_upsampled_input_and_fused_activation(C0, Cout, h, w_):
+    """dec4.conv1 of the U-Net on the lean kernel: nearest-upsampled input (index arithmetic in the LDS fill) with the
+    producer's BatchNorm + ReLU applied while staging (rounded to bf16 like the general kernel does); run-to-run identical"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C0 + Cout + h)
+    B = 3
+    a = torch.randn((B, C0, h, w_), generator=g)
+    sc = 1 + 0.3 * torch.randn(C0, generator=g)
+    sh = 0.3 * torch.randn(C0, generator=g) + 0.2
+    wt = torch.randn((Cout, C0, 3, 3), generator=g) * (2.0 / (9 * C0)) ** 0.5
+    ag, a64 = bf(a)
+    z = F.relu(a64.float() * sc[None, :, None, None] + sh[None, :, None, None]).to(BF).double()
+    ref = F.conv2d(F.interpolate(z, scale_factor=2, mode="nearest"), wt.to(BF).double(), padding=1)
+    wp = ops.pack_weights_bf16(wt.permute(2, 3, 1, 0).contiguous().to(DEV))
+    y, _, st = ops.conv2d_bf16(ag, wp, 3, 1, 1, Cout, mode0=1, in_scale=sc.to(DEV), in_shift=sh.to(DEV), want_stats=True)
+    close_bf16(to_nchw(y), ref)
+    np.testing.assert_allclose(st[0].double().sum(0).cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-4,
+                               atol=1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max()))
+    np.testing.assert_allclose(st[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-4)
+    y2, _, _ = ops.conv2d_bf16(ag, wp, 3, 1, 1, Cout, mode0=1, in_scale=sc.to(DEV), in_shift=sh.to(DEV))
+    assert torch.equal(y, y2)
+    plain = F.conv2d(F.interpolate(a64, scale_factor=2, mode="nearest"), wt.to(BF).double(), padding=1)
+    y3, _, _ = ops.conv2d_bf16(ag, wp, 3, 1, 1, Cout, mode0=1)
+    close_bf16(to_nchw(y3), plain)
 
 
 @pytest.mark.parametrize("k,p", [(3, 1), (1, 0)])

@@ -385,3 +385,65 @@ def test_cached_eval_affine_is_invalidated_by_training_and_by_state_loads(precis
         m.flat_params.mul_(1.01)
         e = m(img)
     assert not torch.equal(d, e) and torch.equal(e, fresh_copy_logits())
+
+
+@pytest.mark.parametrize("h,w,d", [(512, 512, 256), (300, 470, 128), (64, 64, 64)])
+def test_split_normalize_gather_matches_tiler_blocks_and_val_transform(h, w, d):
+    """dt_split_normalize_u8 = zero-pad (tiler.py:121-134) + make_blocks_vectorized (utils/data_handling.py:9-20) +
+    albumentations Normalize + channel selection (scripts/inference.py:94-96, inference.py:57-59) in one gather:
+    bit-identical to the host restatement of those steps, for full and ragged rasters, whole grids and sub-ranges."""
+    from deadtrees_amd import ops
+    from deadtrees_amd.data.deadtreedata import val_transform
+    from deadtrees_amd.data.synthetic import MEAN, STD
+    from deadtrees_amd.deployment.tiler import make_blocks_vectorized
+    rng = np.random.default_rng(h + w)
+    raster = rng.integers(0, 256, (4, h, w), dtype=np.uint8)
+    nby, nbx = -(-h // d), -(-w // d)
+    padded = np.zeros((4, nby * d, nbx * d), np.uint8)
+    padded[:, :h, :w] = raster
+    blocks = make_blocks_vectorized(padded, d)                                    # [n,4,d,d]
+    want = torch.stack([val_transform(image=b.transpose(1, 2, 0))["image"][:3] for b in blocks])   # [n,3,d,d] f32
+    dev_r = torch.from_numpy(raster).to(DEV)
+    got = ops.split_normalize_u8(dev_r, d, 0, nby * nbx, MEAN, STD, 3).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, want)
+    if nby * nbx > 2:
+        part = ops.split_normalize_u8(dev_r, d, 1, nby * nbx - 2, MEAN, STD, 3).cpu().permute(0, 3, 1, 2)
+        assert torch.equal(part, want[1:-1])
+    with pytest.raises(RuntimeError):
+        ops.split_normalize_u8(dev_r, d, 0, nby * nbx + 1, MEAN, STD, 3)
+
+
+def test_blank_raster_flag_and_nhwc_entry():
+    """scripts/inference.py:60-62 is_valid_tile as a device reduction; the NHWC entry of predict_classes gives the class
+    maps of the NCHW one; infer_tile through run_blocks equals the host Tiler path"""
+    from deadtrees_amd import ops
+    from deadtrees_amd.data.synthetic import MEAN, STD
+    from deadtrees_amd.deployment.tiler import infer_tile
+    from deadtrees_amd.network.unet import UNetHIP
+    band = torch.zeros(777, 333, dtype=torch.uint8, device=DEV)
+    band[5::7] = 255
+    assert int(ops.band_has_data(band)) == 0
+    band[700, 300] = 17
+    assert int(ops.band_has_data(band)) == 1
+    m = UNetHIP().to(DEV).eval()
+    rng = np.random.default_rng(3)
+    raster = rng.integers(0, 256, (4, 200, 330), dtype=np.uint8)
+    x = ops.split_normalize_u8(torch.from_numpy(raster).to(DEV), 128, 0, 6, MEAN, STD, 3)
+    a = m.predict_classes(x, dtype="uint8", nhwc=True)
+    b = m.predict_classes(x.permute(0, 3, 1, 2).contiguous(), dtype="uint8")
+    assert torch.equal(a, b)
+
+    class _Inf:   # the two entry points of PyTorchInference on this model
+        def run_u8(self, t, device=None):
+            return m.predict_classes(ops.normalize_u8(t.to(DEV), MEAN, STD, 3), dtype="uint8", nhwc=True)
+
+        def run_blocks(self, r, d, first, count):
+            return m.predict_classes(ops.split_normalize_u8(r, d, first, count, MEAN, STD, 3), dtype="uint8", nhwc=True)
+
+    class _Old:
+        run_u8 = _Inf.run_u8
+
+    on_dev = infer_tile(_Inf(), raster, subtile=128, batch_size=4, device=DEV)
+    no_blocks = infer_tile(_Old(), raster, subtile=128, batch_size=4, device=DEV)
+    host = infer_tile(_Inf(), raster, subtile=128, batch_size=4, device=DEV, on_device=False)
+    assert on_dev.shape == (200, 330) and np.array_equal(on_dev, host) and np.array_equal(no_blocks, host)
