@@ -33,5 +33,6 @@ int dt_wgrad_bf16_dma_launch(const dt_conv_desc* d, const void* src0, const void
 // ---- lean persistent kernel for the narrow full-resolution decoder layers (conv_bf16_narrow.hip): Cin, Cout in {16, 32},
 // weights in registers, 16-wide N; reported by dt_conv2d_bf16_config as mt = 16
 int dt_conv_bf16_narrow_supported(const dt_conv_desc* d);
-int dt_conv_bf16_narrow_grid(const dt_conv_desc* d);     // workgroups = rows of the statistics buffer
+int dt_conv_bf16_narrow_grid(const dt_conv_desc* d, int tf, int bnb);   // persistent workgroups of the variant
+int dt_conv_bf16_narrow_rows(const dt_conv_desc* d);                    // rows of the statistics buffer (>= any grid)
 int dt_conv_bf16_narrow_launch(const dt_conv_desc* d, ConvBfArgs a, hipStream_t st);

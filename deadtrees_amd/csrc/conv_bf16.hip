@@ -485,7 +485,7 @@ extern "C" int dt_conv2d_bf16_stat_rows(const dt_conv_desc* d) {
   int tw, tn, ck, mt;
   bf_cfg(d, &tw, &tn, &ck, &mt);
   if (mt == 8) return dt_conv_bf16_dma_stat_rows(d);
-  if (mt == 16) return dt_conv_bf16_narrow_grid(d);
+  if (mt == 16) return dt_conv_bf16_narrow_rows(d);
   return d->B * dt_cdiv(d->Ho, 128 * mt / tw) * dt_cdiv(d->Wo, tw);
 }
 

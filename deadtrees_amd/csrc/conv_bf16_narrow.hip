@@ -54,7 +54,7 @@ __device__ __forceinline__ float nr_swap_pair(float v) {   // the value of the l
 // CB = Cin / 16, NB = Cout / 16 (1 or 2 each); TF: BatchNorm + ReLU of the producer applied while staging;
 // BNB: fused BatchNorm-backward sums of the layer the written gradient belongs to (virtual activation)
 template <int CB, int NB, bool TF, bool BNB>
-__global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : 3) void conv3x3_bf16_narrow_kernel(const ConvBfArgs a, const int total_tiles) {
+__global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : (CB == 1 && NB == 1 ? 4 : 3)) void conv3x3_bf16_narrow_kernel(const ConvBfArgs a, const int total_tiles) {
   using G = NrGeom<CB, NB>;
   constexpr int CIN = 16 * CB, COUT = 16 * NB;
   __shared__ __attribute__((aligned(16))) unsigned char lds[NR_PIX * G::PITCH + 256 * G::OUTP];
@@ -259,7 +259,9 @@ __global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : 3) void conv3x3_bf1
     }
   }
 
-  // ---- ONE row of partial sums per workgroup (P = gridDim.x rows): fixed-order reductions, no atomics
+  // ---- ONE row of partial sums per workgroup: fixed-order reductions, no atomics.  The buffer has a.P rows (the same
+  // for every variant of a layer shape: the host sizes it before it knows the variant's grid): rows beyond the grid are
+  // written as zeros by the workgroups (row b + k * grid by workgroup b)
   if (want_stats) {
     float* red = reinterpret_cast<float*>(lds);   // >= 2 x 256 x 8 floats = 16 KB: inside the (idle) images
     __syncthreads();
@@ -274,7 +276,8 @@ __global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : 3) void conv3x3_bf1
         const int which = tid / COUT, c = tid % COUT;
         float t = 0.f;
         for (int r = 0; r < PER_IT; ++r) t += red[which * 2048 + (r * G::SEGS + c / 8) * 8 + (c & 7)];
-        a.stats[((size_t)which * NG + blockIdx.x) * COUT + c] = t;
+        a.stats[((size_t)which * a.P + blockIdx.x) * COUT + c] = t;
+        for (int r = (int)blockIdx.x + NG; r < a.P; r += NG) a.stats[((size_t)which * a.P + r) * COUT + c] = 0.f;
       }
     } else {
 #pragma unroll
@@ -293,7 +296,8 @@ __global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : 3) void conv3x3_bf1
       if (tid < 2 * COUT) {
         const int which = tid / COUT, c = tid % COUT, nb = c >> 4, n = c & 15;
         const float* r = red + which * 512 + nb * 16 + n;
-        a.stats[((size_t)which * NG + blockIdx.x) * COUT + c] = (r[0] + r[NB * 16]) + (r[2 * NB * 16] + r[3 * NB * 16]);
+        a.stats[((size_t)which * a.P + blockIdx.x) * COUT + c] = (r[0] + r[NB * 16]) + (r[2 * NB * 16] + r[3 * NB * 16]);
+        for (int q = (int)blockIdx.x + NG; q < a.P; q += NG) a.stats[((size_t)which * a.P + q) * COUT + c] = 0.f;
       }
     }
   }
@@ -319,11 +323,50 @@ int dt_conv_bf16_narrow_supported(const dt_conv_desc* d) {
 
 static int nr_tiles(const dt_conv_desc* d) { return d->B * dt_cdiv(d->Ho, NR_TH) * dt_cdiv(d->Wo, NR_TW); }
 
-// persistent grid = the workgroups that are co-resident (3 per CU by launch bounds / LDS; 2 for 32 -> 32, whose 72
-// weight registers need the larger register budget), never more than the tiles; it is also the number of rows of the
-// statistics buffer
-int dt_conv_bf16_narrow_grid(const dt_conv_desc* d) {
-  const int t = nr_tiles(d), per_cu = (d->C0 == 32 && d->Cout == 32) ? 2 : 3;
+// Workgroups of an instantiation that fit one CU, from its own code object: registers (512 per lane and SIMD, granule 8,
+// one wave of the workgroup per SIMD) and LDS (160 KiB).  The kernel is latency-bound by the bytes it keeps in flight
+// (PMC round 3: waves parked 53 % of the time at 3 workgroups per CU = 33 KB in flight per CU -> 3.6 TB/s), so the
+// persistent grid takes every slot there is — and exactly those, so that all workgroups walk the same number of tiles.
+template <class K>
+static int nr_occupancy(K kernel) {
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kernel)) != hipSuccess) return 2;
+  const int regs = ((at.numRegs + 7) / 8) * 8;
+  int by_regs = regs > 0 ? 512 / regs : 8;
+  const int by_lds = at.sharedSizeBytes > 0 ? (int)(163840 / at.sharedSizeBytes) : 8;
+  int occ = by_regs < by_lds ? by_regs : by_lds;
+  if (occ > 8) occ = 8;
+  if (occ < 1) occ = 1;
+  return occ;
+}
+
+template <int CB, int NB>
+static int nr_occ_of(bool tf, bool bnb) {
+  static int cache[3] = {0, 0, 0};
+  const int v = tf ? 1 : (bnb ? 2 : 0);
+  if (cache[v] == 0)
+    cache[v] = tf ? nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, true, false>)
+                  : (bnb ? nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, false, true>)
+                         : nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, false, false>));
+  return cache[v];
+}
+
+static int nr_per_cu(const dt_conv_desc* d, bool tf, bool bnb) {
+  if (d->C0 == 16 && d->Cout == 16) return nr_occ_of<1, 1>(tf, bnb);
+  if (d->C0 == 16) return nr_occ_of<1, 2>(tf, bnb);
+  if (d->Cout == 16) return nr_occ_of<2, 1>(tf, bnb);
+  return nr_occ_of<2, 2>(tf, bnb);
+}
+
+// rows of the statistics buffer: an upper bound of every variant's persistent grid (8 workgroups per CU), the same for
+// all variants of a layer shape (dt_conv2d_bf16_stat_rows is asked before the variant is known)
+int dt_conv_bf16_narrow_rows(const dt_conv_desc* d) {
+  const int t = nr_tiles(d);
+  return t < 8 * NR_CUS ? t : 8 * NR_CUS;
+}
+
+int dt_conv_bf16_narrow_grid(const dt_conv_desc* d, int tf, int bnb) {
+  const int t = nr_tiles(d), per_cu = nr_per_cu(d, tf != 0, bnb != 0);
   return t < per_cu * NR_CUS ? t : per_cu * NR_CUS;
 }
 
@@ -345,8 +388,8 @@ int dt_conv_bf16_narrow_launch(const dt_conv_desc* d, ConvBfArgs a, hipStream_t 
   DT_REQUIRE(!(tf && bnb), "conv_bf16_narrow: no input transform on the BatchNorm-backward form");
   a.tiles_x = dt_cdiv(d->Wo, NR_TW);
   a.tiles_y = dt_cdiv(d->Ho, NR_TH);
-  const int total = nr_tiles(d), grid = dt_conv_bf16_narrow_grid(d);
-  a.P = grid;
+  const int total = nr_tiles(d), grid = dt_conv_bf16_narrow_grid(d, tf, bnb);
+  a.P = dt_conv_bf16_narrow_rows(d);
   int rc;
   if (d->C0 == 16 && d->Cout == 16) rc = nr_launch<1, 1>(a, grid, total, tf, bnb, st);
   else if (d->C0 == 16) rc = nr_launch<1, 2>(a, grid, total, tf, bnb, st);
