@@ -1155,6 +1155,10 @@ extern "C" size_t dt_conv2d_wgrad_bf16_workspace(const dt_conv_desc* d) {
   wb_cfg(d, &tw, &ks, &T, &cib, &cob);
   const size_t E = (size_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
   size_t need = (size_t)ks * E * sizeof(float);
+  if (dt_wgrad_bf16_narrow_supported(d)) {
+    const size_t n3 = dt_wgrad_bf16_narrow_workspace(d);
+    if (n3 > need) need = n3;
+  }
   if (wb_use_dma() && dt_wgrad_bf16_dma_supported(d)) {   // the larger of the two: in_scale decides the kernel at launch
     const size_t n2 = dt_wgrad_bf16_dma_workspace(d);
     if (n2 > need) need = n2;
@@ -1226,6 +1230,15 @@ extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, con
   DT_REQUIRE(workspace_bytes >= dt_conv2d_wgrad_bf16_workspace(d), "wgrad_bf16: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t E = (int64_t)d->ksize * d->ksize * (d->C0 + d->C1) * d->Cout;
+  if (dt_wgrad_bf16_narrow_supported(d)) {
+    // Cin, Cout in {16, 32} at full resolution: the lean persistent kernel (conv_bf16_narrow.hip), one slab per workgroup
+    const int parts = dt_wgrad_bf16_narrow_launch(d, src0, dy, workspace, in_scale, in_shift, st);
+    if (parts < 0) return parts;
+    hipLaunchKernelGGL(wgrad_bf16_final_kernel, dim3((unsigned)((E / 4 + 15) / 16)), dim3(256), 0, st, workspace, dw_hwio,
+                       parts, E);
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
   if (in_scale == nullptr && wb_use_dma() && dt_wgrad_bf16_dma_supported(d)) {
     // 3x3 stride-1 layers with 64-channel blocks and a stored (untransformed) input: the LDS-DMA persistent kernel
     const int parts = dt_wgrad_bf16_dma_launch(d, src0, src1, dy, workspace, st);

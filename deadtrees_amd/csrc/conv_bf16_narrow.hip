@@ -399,3 +399,268 @@ int dt_conv_bf16_narrow_launch(const dt_conv_desc* d, ConvBfArgs a, hipStream_t 
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
+
+// ================================================================================================================
+// Weight gradient of the same narrow layers: dW[tap][ci][co] (fp32) = sum_pixels x[pix + tap][ci] * dy[pix][co].
+// Replaces ATen convolution_backward(weight) for dec3.conv2 / dec4.conv1 / dec4.conv2 under AMP, where the general
+// kernel conv_wgrad_bf16_kernel<3, 1, 32, *, 32> (32x32x16 MFMAs on 16-channel operands, 128-pixel tiles between two
+// barriers, run-time variants) ran at 0.15-0.5 PFLOP/s on layers that are HBM-bound (dec4.conv2 at B = 64: 1.07 GB).
+//   * v_mfma_f32_16x16x32_bf16 with M = 16 input channels, N = 16 output channels, K = 32 PIXELS = one tile row;
+//     both operands need 8 consecutive pixels per lane for a fixed channel: pixel-major LDS images read with
+//     ds_read_b64_tr_b16.  The pixel order inside a K step is permuted (lane group kg holds columns 4 kg .. 4 kg + 3 and
+//     16 + 4 kg .. 16 + 4 kg + 3) — the same for both operands — so that a 32-lane half of a transposed read covers 8
+//     CONSECUTIVE pixel rows: 256 contiguous bytes at the 32-byte pitch, 8 distinct bank octets at the 96-byte pitch;
+//   * an x fragment (halo row, tap column, channel block) feeds the MFMAs of up to three tap rows; the dy fragments of a
+//     row are read once; 9 x CB x NB accumulators (4 registers each) live for the whole kernel;
+//   * persistent over 8 x 32-pixel tiles with the next tile in flight in registers; the four waves split the tile's rows
+//     and are summed through LDS once at the end (fixed order); one slab per workgroup -> wgrad_bf16_final_kernel.
+typedef __bf16 bf16x4n __attribute__((ext_vector_type(4)));
+typedef bf16x4n __attribute__((address_space(3)))* nr_trptr;
+
+struct NrWgArgs {
+  const __bf16* src0;
+  const __bf16* dy;
+  const float* in_scale;
+  const float* in_shift;
+  float* ws;                 // [gridDim.x][9][Cin][Cout] fp32 slabs
+  int B, Hin, Win, mode0, tiles_x, tiles_y;
+};
+
+template <int CB, int NB, bool TF>
+__global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : 3) void conv3x3_wgrad_bf16_narrow_kernel(const NrWgArgs a,
+                                                                                                    const int total_tiles) {
+  constexpr int CIN = 16 * CB, COUT = 16 * NB;
+  constexpr int PX = CB == 1 ? 32 : 96, PY = NB == 1 ? 32 : 96;       // bytes per pixel row of the two LDS images
+  constexpr int XS = 2 * CB, YS = 2 * NB;                             // 16-byte slots per pixel
+  constexpr int FX = (NR_PIX * XS + 255) / 256, FY = YS;              // fill iterations (256 output pixels x YS / 256)
+  constexpr int LDS_X = NR_PIX * PX, LDS_Y = 256 * PY;
+  constexpr int RED = 4 * CB * NB * 256 * 4;                          // one tap of three waves' accumulators... (per wave)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(LDS_X + LDS_Y) > 3 * RED ? (LDS_X + LDS_Y) : 3 * RED];
+  unsigned char* lx = lds;
+  unsigned char* ly = lds + LDS_X;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const int Hs = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws = a.mode0 ? (a.Win >> 1) : a.Win;
+  const int NG = gridDim.x;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + NG - 1) / NG;
+  auto tile_of = [&](int round) { return (int)xcd_remap(blockIdx.x + (unsigned)round * NG, (unsigned)total_tiles); };
+
+  // ---- fill roles (fixed per thread)
+  int x_hy[FX], x_hx[FX], x_dst[FX];
+#pragma unroll
+  for (int it = 0; it < FX; ++it) {
+    const int e = tid + 256 * it;
+    const int pix = e / XS, slot = e - pix * XS;
+    x_hy[it] = e < NR_PIX * XS ? pix / NR_HW : -100000;
+    x_hx[it] = pix % NR_HW;
+    x_dst[it] = pix * PX + 16 * slot;
+  }
+  const int x_ch = 8 * (tid % XS), y_ch = 8 * (tid % YS);
+  const int y_pix0 = tid / YS;                                         // + it * (256 / YS)
+  float tf_sc[TF ? 8 : 1], tf_sh[TF ? 8 : 1];
+  if constexpr (TF) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tf_sc[k] = a.in_scale[x_ch + k];
+      tf_sh[k] = a.in_shift[x_ch + k];
+    }
+  }
+  u32x4 rx[FX], ry[FY];
+  unsigned xvalid = 0;
+  auto issue_loads = [&](int round) {
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * NR_TH, ox0 = tx * NR_TW;
+    xvalid = 0;
+#pragma unroll
+    for (int it = 0; it < FX; ++it) {
+      const int iy = oy0 - 1 + x_hy[it], ix = ox0 - 1 + x_hx[it];
+      const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(a.src0 + ((size_t)(b * Hs + sy) * Ws + sx) * CIN + x_ch);
+      xvalid |= (ok ? 1u : 0u) << it;
+      rx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < FY; ++it) {
+      const int pl = y_pix0 + it * (256 / YS);
+      const int oy = oy0 + pl / NR_TW, ox = ox0 + pl % NR_TW;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (oy < a.Hin && ox < a.Win) v = *reinterpret_cast<const u32x4*>(a.dy + ((size_t)(b * a.Hin + oy) * a.Win + ox) * COUT + y_ch);
+      ry[it] = v;
+    }
+  };
+
+  // ---- transposed-read lane bases: group kg reads pixel rows 4 kg + q4 (lo) and 16 + 4 kg + q4 (hi) of the K step,
+  // 4 channels 4 p4 .. 4 p4 + 3 of the 16-channel block; lane i of the group receives channel i
+  const int xlane = (4 * kg + q4) * PX + 8 * p4;
+  const int ylane = (4 * kg + q4) * PY + 8 * p4;
+  auto tr8 = [&](const unsigned char* p, int pitch) -> bf16x8 {
+    const bf16x4n lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((nr_trptr)p);
+    const bf16x4n hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((nr_trptr)(p + 16 * pitch));
+    bf16x8 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = lo[k];
+      v[4 + k] = hi[k];
+    }
+    return v;
+  };
+
+  f32x4 acc[9][CB][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[t][cb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (my_tiles > 0) issue_loads(0);
+  for (int round = 0; round < my_tiles; ++round) {
+    __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < FX; ++it) {
+      if (x_hy[it] >= 0) {
+        u32x4 raw = rx[it];
+        if constexpr (TF) {
+          if ((xvalid >> it) & 1u) {
+            bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float f = (float)v[k] * tf_sc[k] + tf_sh[k];
+              f = f < 0.f ? 0.f : f;
+              v[k] = (__bf16)f;
+            }
+            raw = __builtin_bit_cast(u32x4, v);
+          }
+        }
+        *reinterpret_cast<u32x4*>(lx + x_dst[it]) = raw;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < FY; ++it)
+      *reinterpret_cast<u32x4*>(ly + (y_pix0 + it * (256 / YS)) * PY + 16 * (tid % YS)) = ry[it];
+    __syncthreads();
+    if (round + 1 < my_tiles) issue_loads(round + 1);
+
+    // this wave's rows r = 0, 1 (tile rows 2 w + r): dy fragments once, x fragments per (halo row, tap column, block)
+    bf16x8 fb[2][NB];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) fb[r][nb] = tr8(ly + ylane + ((2 * wave + r) * NR_TW) * PY + 32 * nb, PY);
+#pragma unroll
+    for (int hr = 0; hr < 4; ++hr)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const bf16x8 av = tr8(lx + xlane + ((2 * wave + hr) * NR_HW + kw) * PX + 32 * cb, PX);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int r = hr - kh;
+            if (r >= 0 && r < 2) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[3 * kh + kw][cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, fb[r][nb], acc[3 * kh + kw][cb][nb], 0, 0, 0);
+            }
+          }
+        }
+  }
+
+  // ---- sum the four waves' accumulators through LDS, one tap at a time (fixed order 1, 2, 3), and write the workgroup's
+  // slab: D row (ci) = 4 kg + i, column (co) = lane & 15
+  float* red = reinterpret_cast<float*>(lds);
+  const int n = lane & 15;
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if (wave != 0) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) v = tt == t ? acc[tt][cb][nb][i] : v;   // static register selects
+            red[(((wave - 1) * CB * NB + cb * NB + nb) * 4 + i) * 64 + lane] = v;
+          }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 9; ++tt) v = tt == t ? acc[tt][cb][nb][i] : v;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) v += red[((w * CB * NB + cb * NB + nb) * 4 + i) * 64 + lane];
+            const int ci = 16 * cb + 4 * kg + i, co = 16 * nb + n;
+            a.ws[(((size_t)blockIdx.x * 9 + t) * CIN + ci) * COUT + co] = v;
+          }
+    }
+  }
+}
+
+int dt_wgrad_bf16_narrow_supported(const dt_conv_desc* d) {
+  if (!nr_enabled() || d == nullptr) return 0;
+  if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->C1 != 0) return 0;
+  if ((d->C0 != 16 && d->C0 != 32) || (d->Cout != 16 && d->Cout != 32)) return 0;
+  if (d->mode0 != 0 && d->mode0 != 1) return 0;
+  if (d->Ho != d->Hin || d->Wo != d->Win || d->Wo < 32 || d->Ho < 8) return 0;
+  return 1;
+}
+
+template <int CB, int NB>
+static int nrw_occ(bool tf) {
+  static int cache[2] = {0, 0};
+  if (cache[tf] == 0)
+    cache[tf] = tf ? nr_occupancy(conv3x3_wgrad_bf16_narrow_kernel<CB, NB, true>)
+                   : nr_occupancy(conv3x3_wgrad_bf16_narrow_kernel<CB, NB, false>);
+  return cache[tf];
+}
+
+size_t dt_wgrad_bf16_narrow_workspace(const dt_conv_desc* d) {
+  const int t = nr_tiles(d);
+  const size_t parts = (size_t)(t < 8 * NR_CUS ? t : 8 * NR_CUS);
+  return parts * 9 * d->C0 * d->Cout * sizeof(float);
+}
+
+// -> number of slabs written to `ws` (one per workgroup), or a negative error code
+int dt_wgrad_bf16_narrow_launch(const dt_conv_desc* d, const void* src0, const void* dy, float* ws, const float* in_scale,
+                                const float* in_shift, hipStream_t st) {
+  DT_REQUIRE(dt_wgrad_bf16_narrow_supported(d), "wgrad_bf16_narrow: layer shape not supported");
+  NrWgArgs a;
+  a.src0 = (const __bf16*)src0; a.dy = (const __bf16*)dy; a.in_scale = in_scale; a.in_shift = in_shift; a.ws = ws;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.mode0 = d->mode0;
+  a.tiles_x = dt_cdiv(d->Wo, NR_TW); a.tiles_y = dt_cdiv(d->Ho, NR_TH);
+  const int total = nr_tiles(d);
+  const bool tf = in_scale != nullptr;
+  int occ;
+  if (d->C0 == 16 && d->Cout == 16) occ = nrw_occ<1, 1>(tf);
+  else if (d->C0 == 16) occ = nrw_occ<1, 2>(tf);
+  else if (d->Cout == 16) occ = nrw_occ<2, 1>(tf);
+  else occ = nrw_occ<2, 2>(tf);
+  const int grid = total < occ * NR_CUS ? total : occ * NR_CUS;
+  const dim3 g((unsigned)grid), blk(256);
+#define NRW_LAUNCH(CBv, NBv)                                                                                     \
+  do {                                                                                                           \
+    if (tf) hipLaunchKernelGGL((conv3x3_wgrad_bf16_narrow_kernel<CBv, NBv, true>), g, blk, 0, st, a, total);      \
+    else hipLaunchKernelGGL((conv3x3_wgrad_bf16_narrow_kernel<CBv, NBv, false>), g, blk, 0, st, a, total);       \
+  } while (0)
+  if (d->C0 == 16 && d->Cout == 16) NRW_LAUNCH(1, 1);
+  else if (d->C0 == 16) NRW_LAUNCH(1, 2);
+  else if (d->Cout == 16) NRW_LAUNCH(2, 1);
+  else NRW_LAUNCH(2, 2);
+#undef NRW_LAUNCH
+  DT_LAUNCH_CHECK();
+  return grid;
+}

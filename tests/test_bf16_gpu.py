@@ -173,6 +173,36 @@ def test_wgrad_bf16_upsample_concat_transform(C0, C1, Cout, h, w_):
     assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("C0,Cout,h,w_,mode0,tf", [(16, 16, 40, 64, 0, False), (32, 16, 20, 24, 1, True), (32, 32, 33, 35, 0, True),
+                                                   (16, 32, 16, 32, 0, False), (32, 16, 64, 64, 1, False), (16, 16, 128, 128, 0, True)])
+def test_wgrad_bf16_narrow_kernel(C0, Cout, h, w_, mode0, tf):
+    """the lean weight-gradient kernel of the narrow decoder layers (conv_bf16_narrow.hip) against fp64 on the same
+    bf16-rounded operands: every channel combination, ragged maps, up-sampled input, fused producer BatchNorm + ReLU,
+    several tiles per persistent workgroup; run-to-run bit-identical"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C0 * 3 + Cout + h)
+    B = 5 if h >= 64 else 2
+    a = torch.randn((B, C0, h, w_), generator=g)
+    ag, a64 = bf(a)
+    sc = sh = None
+    z = a64
+    if tf:
+        sc = 1 + 0.3 * torch.randn(C0, generator=g)
+        sh = 0.3 * torch.randn(C0, generator=g) + 0.3
+        z = F.relu(a64.float() * sc[None, :, None, None] + sh[None, :, None, None]).to(BF).double()
+    xin = F.interpolate(z, scale_factor=2, mode="nearest") if mode0 else z
+    wt = (torch.randn((Cout, C0, 3, 3), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    y = F.conv2d(xin, wt, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    dyg, dy64 = bf(dy)
+    y.backward(dy64)
+    kw = dict(mode0=mode0, in_scale=sc.to(DEV) if tf else None, in_shift=sh.to(DEV) if tf else None)
+    dw = ops.conv2d_wgrad_bf16(ag, dyg, 3, 1, 1, **kw)
+    got = dw.cpu().permute(3, 2, 0, 1).double()
+    assert float((got - wt.grad).abs().max() / wt.grad.abs().max()) < 2e-5
+    assert torch.equal(dw, ops.conv2d_wgrad_bf16(ag, dyg, 3, 1, 1, **kw))
+
+
 WG_DMA_CASES = [  # B, h, w (stored size of source 0), C0, C1, mode0, Cout — the LDS-DMA persistent weight-gradient kernel
     (2, 32, 32, 64, 0, 0, 64), (2, 37, 50, 64, 0, 0, 128), (3, 16, 16, 128, 0, 0, 64), (2, 8, 8, 64, 0, 0, 64),
     (5, 13, 11, 64, 0, 0, 64), (1, 12, 10, 128, 64, 1, 64), (2, 8, 8, 64, 64, 1, 128), (1, 20, 44, 64, 64, 0, 64),
