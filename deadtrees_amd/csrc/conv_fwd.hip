@@ -597,6 +597,7 @@ static int validate(const dt_conv_desc* d) {
 
 extern "C" int dt_conv2d_stat_rows(const dt_conv_desc* d) {
   if (validate(d) != DT_OK) return DT_EINVAL;
+  if (dt_conv2d_narrow_supported(d)) return dt_conv2d_narrow_rows(d);   // one row per persistent workgroup (upper bound)
   ConvCfg c = pick_cfg(d);
   return d->B * dt_cdiv(d->Ho, 256 / c.tw) * dt_cdiv(d->Wo, c.tw);
 }
@@ -667,6 +668,8 @@ static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* sr
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv: in_scale/in_shift must come together");
   DT_REQUIRE(in_scale == nullptr || (d->ksize == 3 && d->stride == 1 && d->mode0 != 2 && d->C0 <= DT_TF_MAXC),
              "conv: input transform needs a 3x3 stride-1 layer with C0 <= %d and no zero-insertion", DT_TF_MAXC);
+  if (out_bf16 == nullptr && dt_conv2d_narrow_supported(d))   // Cin, Cout in {16, 32} at full resolution: the lean kernel
+    return dt_conv2d_narrow_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream, fuse);
   if (dt_conv2d_n16_supported(d))
     return dt_conv2d_n16_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream, fuse);
   ConvCfg c = pick_cfg(d);
@@ -751,6 +754,12 @@ extern "C" int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck
   int rc = validate(d);
   if (rc != DT_OK) return rc;
   ConvCfg c = pick_cfg(d);
+  if (dt_conv2d_narrow_supported(d)) {   // conv3x3_f32_narrow_kernel<CB, NB, ...>: reported as ck = 1000 + 10 CB + NB
+    if (tw) *tw = 32;
+    if (tn) *tn = d->Cout;
+    if (ck) *ck = 1000 + 10 * (d->C0 / 16) + d->Cout / 16;
+    return DT_OK;
+  }
   if (dt_conv2d_n16_supported(d)) {   // conv_fwd_n16_kernel: 8x32 pixel tile, 16 output channels, CK 16
     if (tw) *tw = 32;
     if (tn) *tn = 16;

@@ -373,3 +373,299 @@ int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* d
   DT_LAUNCH_CHECK();
   return DT_OK;
 }
+
+// ================================================================================================================
+// Round 3: lean persistent fp32 kernel for the narrow full-resolution decoder layers — Cin, Cout in {16, 32}, 3x3
+// stride 1 (dec3.conv2, dec4.conv1 / conv2 and their data gradients; in inference the same layers).  The fp32 twin of
+// conv_bf16_narrow.hip: the round-1/2 kernels above and conv_fwd_kernel<3, 1, 32, 32, 8, *> keep the matrix pipe busy
+// 39-57 % on these MFMA-bound layers (PMC: ~500 non-MFMA vector instructions per wave and 256-pixel tile, weights
+// re-staged through LDS per tile, one ds_read_b32 per MFMA).  Here:
+//   * weights in REGISTERS for the whole kernel (v_mfma_f32_16x16x4_f32: one register per K step of 4 channels and N
+//     block: 36 registers for 16 -> 16, 144 for 32 -> 32);
+//   * the K order inside a 16-channel block is permuted (lane group kq supplies channels 4 kq .. 4 kq + 3, one per K
+//     step) so that ONE ds_read_b128 per tap and block feeds four MFMAs; pixel rows at a 96- / 160-byte pitch are
+//     conflict-free for those reads (brute-forced against the bank rule);
+//   * persistent over 8 x 32-pixel tiles, the next tile's input in flight in registers (not for 32 -> 32: its 144 weight
+//     registers leave no room, and its 18k MFMA cycles per tile cover a load by themselves);
+//   * BatchNorm statistics / fused BatchNorm-backward sums accumulated in registers over all tiles of a workgroup: one
+//     row per workgroup; interior tiles test no bounds.
+struct NarrowLeanArgs {
+  const float* src0;
+  const float* in_scale;
+  const float* in_shift;
+  const float* w;      // [9][Cin][Cout]
+  float* out;
+  float* stats;        // [2][P][Cout] or null
+  dt_bn_bwd_fuse bnb;
+  int B, Hin, Win, mode0, tiles_x, tiles_y, P;
+};
+
+#define NL_PIX (N16_HH * N16_HW)   // 340 halo pixels of an 8 x 32 tile
+
+template <int CB, int NB, bool TF, bool BNB>
+__global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narrow_kernel(
+    const NarrowLeanArgs a, const int total_tiles) {
+  constexpr int CIN = 16 * CB, COUT = 16 * NB;
+  constexpr int PITCH = CB == 1 ? 96 : 160;                 // bytes per halo pixel
+  constexpr int SLOTS = 4 * CB;                             // 16-byte slots (4 channels) per pixel
+  constexpr int FILL = (NL_PIX * SLOTS + 255) / 256;
+  constexpr bool PREFETCH = CB * NB < 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NL_PIX * PITCH > 4096 ? NL_PIX * PITCH : 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  const int Hs = a.mode0 ? (a.Hin >> 1) : a.Hin, Ws = a.mode0 ? (a.Win >> 1) : a.Win;
+  const int NG = gridDim.x;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + NG - 1) / NG;
+  auto tile_of = [&](int round) { return (int)xcd_remap(blockIdx.x + (unsigned)round * NG, (unsigned)total_tiles); };
+
+  // ---- weights -> registers: K step (tap, block cb, j): B[k = kq][n] = w[tap][16 cb + 4 kq + j][16 nb + n]
+  float wreg[9][CB][4][NB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          wreg[t][cb][j][nb] = a.w[((size_t)t * CIN + 16 * cb + 4 * kq + j) * COUT + 16 * nb + m];
+
+  // ---- fragment base: M block mb of wave w = output row 2 w + (mb >> 1), columns 16 (mb & 1) + m; slot kq of block cb
+  const int abase = (2 * wave * N16_HW + m) * PITCH + 16 * kq;
+
+  // ---- fill roles: element e = tid + 256 it = (halo pixel e / SLOTS, slot e % SLOTS); only the pixel index is kept
+  // per iteration (registers are the scarce resource here), row / column are re-derived per tile
+  const int f_pix0 = tid / SLOTS, f_slot = tid % SLOTS;   // pixel of iteration it = f_pix0 + it * (256 / SLOTS)
+  const int f_ch = 4 * f_slot;
+  f32x4 tf_sc = {1.f, 1.f, 1.f, 1.f}, tf_sh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (TF) {
+    tf_sc = *reinterpret_cast<const f32x4*>(a.in_scale + f_ch);
+    tf_sh = *reinterpret_cast<const f32x4*>(a.in_shift + f_ch);
+  }
+  f32x4 rin[FILL];
+  unsigned rvalid = 0;
+  auto issue_loads = [&](int round) {
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int iy0 = ty * N16_TH - 1, ix0 = tx * N16_TW - 1;
+    rvalid = 0;
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int pix = f_pix0 + it * (256 / SLOTS);
+      const int hy = pix / N16_HW, hx = pix - hy * N16_HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = pix < NL_PIX && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.src0 + ((size_t)(b * Hs + sy) * Ws + sx) * CIN + f_ch);
+      rvalid |= (ok ? 1u : 0u) << it;
+      rin[it] = v;
+    }
+  };
+
+  float s1[NB], s2[NB];
+  float b_mu[NB], b_is[NB], b_sc[NB], b_sh[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    s1[nb] = s2[nb] = 0.f;
+    b_mu[nb] = b_is[nb] = b_sc[nb] = b_sh[nb] = 0.f;
+    if constexpr (BNB) {
+      b_mu[nb] = a.bnb.mean[16 * nb + m];
+      b_is[nb] = a.bnb.invstd[16 * nb + m];
+      b_sc[nb] = a.bnb.act_scale[16 * nb + m];
+      b_sh[nb] = a.bnb.act_shift[16 * nb + m];
+    }
+  }
+  const bool want_stats = a.stats != nullptr;
+
+  if (PREFETCH && my_tiles > 0) issue_loads(0);
+  for (int round = 0; round < my_tiles; ++round) {
+    if constexpr (!PREFETCH) issue_loads(round);
+    __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int pix = f_pix0 + it * (256 / SLOTS);
+      if (pix < NL_PIX) {
+        f32x4 v = rin[it];
+        if constexpr (TF) {
+          if ((rvalid >> it) & 1u) {   // the arithmetic of the direct kernels' staging (mul, add, ReLU); padding stays zero
+            v = v * tf_sc + tf_sh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+          }
+        }
+        *reinterpret_cast<f32x4*>(lds + pix * PITCH + 16 * f_slot) = v;
+      }
+    }
+    __syncthreads();
+    if (PREFETCH && round + 1 < my_tiles) issue_loads(round + 1);
+
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // taps in kh -> kw -> channel order like the direct kernels; within a block the channel order is (j, kq) — an
+    // exact fp32 fma chain either way, the rounding sequence differs from conv_fwd_n16_kernel's (kq, j) order
+    // groups g = (tap, block): 4 fragment reads (one per M block) feed 16 NB MFMAs; the reads of group g + 1 are issued
+    // before the MFMAs of group g (two register sets) and the scheduler is fenced per group — left alone, hipcc hoists
+    // dozens of the 36 CB reads and spills (168 registers + 290 B of scratch for 32 -> 16)
+    auto frag = [&](int g, f32x4 (&av)[4]) {
+      const int t = g / CB, cb = g % CB;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        av[mb] = *reinterpret_cast<const f32x4*>(lds + abase + (((mb >> 1) + t / 3) * N16_HW + 16 * (mb & 1) + t % 3) * PITCH + 64 * cb);
+    };
+    f32x4 fav[2][4];
+    frag(0, fav[0]);
+#pragma unroll
+    for (int g = 0; g < 9 * CB; ++g) {
+      if (g + 1 < 9 * CB) frag(g + 1, fav[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      // K step j outermost: consecutive MFMAs go to DIFFERENT accumulators (v_mfma_f32_16x16x4_f32 issues every 32
+      // cycles but a dependent one waits 40: with the M block outermost the four K steps of a block chained on one
+      // accumulator and the loop ran 25 % slower)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fav[g & 1][mb][j], wreg[g / CB][g % CB][j][nb], acc[mb][nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: D col = channel 16 nb + m, row = pixel column 4 kq + i of the M block
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * N16_TH, ox0 = tx * N16_TW;
+    const bool interior = oy0 + N16_TH <= a.Hin && ox0 + N16_TW <= a.Win;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int oy = oy0 + 2 * wave + (mb >> 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ox = ox0 + 16 * (mb & 1) + 4 * kq + i;
+        if (interior || (oy < a.Hin && ox < a.Win)) {
+          const size_t o = (((size_t)b * a.Hin + oy) * a.Win + ox) * COUT + m;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float v = acc[mb][nb][i];
+            if constexpr (BNB) {
+              const float yv = a.bnb.y[o + 16 * nb];
+              const float g = (yv * b_sc[nb] + b_sh[nb]) > 0.f ? v : 0.f;
+              s1[nb] += g;
+              s2[nb] += g * ((yv - b_mu[nb]) * b_is[nb]);
+            } else {
+              s1[nb] += v;
+              s2[nb] += v * v;
+            }
+            a.out[o + 16 * nb] = v;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- one row of partial sums per workgroup; rows beyond the grid (the buffer has a.P rows) are written as zeros
+  if (want_stats) {
+    float* red = reinterpret_cast<float*>(lds);   // [2][4 waves][NB][16]
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float u1 = s1[nb], u2 = s2[nb];
+      u1 += __shfl_xor(u1, 16, 64);
+      u2 += __shfl_xor(u2, 16, 64);
+      u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 32, 64);
+      if (kq == 0) {
+        red[(wave * NB + nb) * 16 + m] = u1;
+        red[512 + (wave * NB + nb) * 16 + m] = u2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const int which = tid / COUT, c = tid % COUT, nb = c >> 4, n = c & 15;
+      const float* r = red + which * 512 + nb * 16 + n;
+      a.stats[((size_t)which * a.P + blockIdx.x) * COUT + c] = (r[0] + r[NB * 16]) + (r[2 * NB * 16] + r[3 * NB * 16]);
+      for (int q = (int)blockIdx.x + NG; q < a.P; q += NG) a.stats[((size_t)which * a.P + q) * COUT + c] = 0.f;
+    }
+  }
+}
+
+static bool nl_enabled() {
+  static const int on = [] {
+    const char* e = getenv("DT_FP32_NARROW");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  return on != 0;
+}
+
+extern "C" int dt_conv2d_narrow_supported(const dt_conv_desc* d) {
+  if (!nl_enabled() || d == nullptr) return 0;
+  if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->C1 != 0 || d->cout_split != 0 || d->accumulate != 0) return 0;
+  if ((d->C0 != 16 && d->C0 != 32) || (d->Cout != 16 && d->Cout != 32)) return 0;
+  if (d->mode0 != 0 && d->mode0 != 1) return 0;
+  if (d->Ho != d->Hin || d->Wo != d->Win || d->Wo < 32 || d->Ho < 8) return 0;
+  return 1;
+}
+
+static int nl_tiles(const dt_conv_desc* d) { return d->B * dt_cdiv(d->Ho, N16_TH) * dt_cdiv(d->Wo, N16_TW); }
+
+// rows of the statistics buffer: the same for every variant of a layer shape (an upper bound of the persistent grid)
+int dt_conv2d_narrow_rows(const dt_conv_desc* d) {
+  const int t = nl_tiles(d);
+  return t < 8 * 256 ? t : 8 * 256;
+}
+
+template <class K>
+static int nl_occupancy(K kernel) {
+  hipFuncAttributes at;
+  if (hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kernel)) != hipSuccess) return 2;
+  const int regs = ((at.numRegs + 7) / 8) * 8;
+  const int by_regs = regs > 0 ? 512 / regs : 8;
+  const int by_lds = at.sharedSizeBytes > 0 ? (int)(163840 / at.sharedSizeBytes) : 8;
+  int occ = by_regs < by_lds ? by_regs : by_lds;
+  return occ > 8 ? 8 : (occ < 1 ? 1 : occ);
+}
+
+template <int CB, int NB>
+static int nl_launch(const NarrowLeanArgs& a, int total, bool tf, bool bnb, hipStream_t st) {
+  static int occ[3] = {0, 0, 0};
+  const int v = tf ? 1 : (bnb ? 2 : 0);
+  if (occ[v] == 0)
+    occ[v] = tf ? nl_occupancy(conv3x3_f32_narrow_kernel<CB, NB, true, false>)
+                : (bnb ? nl_occupancy(conv3x3_f32_narrow_kernel<CB, NB, false, true>)
+                       : nl_occupancy(conv3x3_f32_narrow_kernel<CB, NB, false, false>));
+  const int grid = total < occ[v] * 256 ? total : occ[v] * 256;
+  const dim3 g((unsigned)grid), blk(256);
+  if (tf) hipLaunchKernelGGL((conv3x3_f32_narrow_kernel<CB, NB, true, false>), g, blk, 0, st, a, total);
+  else if (bnb) hipLaunchKernelGGL((conv3x3_f32_narrow_kernel<CB, NB, false, true>), g, blk, 0, st, a, total);
+  else hipLaunchKernelGGL((conv3x3_f32_narrow_kernel<CB, NB, false, false>), g, blk, 0, st, a, total);
+  return DT_OK;
+}
+
+int dt_conv2d_narrow_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
+                            const float* in_scale, const float* in_shift, hipStream_t st, const dt_bn_bwd_fuse* fuse) {
+  DT_REQUIRE(dt_conv2d_narrow_supported(d), "conv_narrow: layer shape not supported");
+  const bool tf = in_scale != nullptr, bnb = fuse != nullptr && fuse->y != nullptr;
+  DT_REQUIRE(!bnb || (fuse->act == nullptr && fuse->act_scale && fuse->act_shift && stats),
+             "conv_narrow: the fused BatchNorm-backward sums take a virtual activation and a stats buffer");
+  DT_REQUIRE(!(tf && bnb), "conv_narrow: no input transform on the BatchNorm-backward form");
+  NarrowLeanArgs a;
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.src0 = src0; a.w = w; a.out = out; a.stats = stats; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.mode0 = d->mode0;
+  a.tiles_x = dt_cdiv(d->Wo, N16_TW); a.tiles_y = dt_cdiv(d->Ho, N16_TH);
+  a.P = dt_conv2d_narrow_rows(d);
+  const int total = nl_tiles(d);
+  int rc;
+  if (d->C0 == 16 && d->Cout == 16) rc = nl_launch<1, 1>(a, total, tf, bnb, st);
+  else if (d->C0 == 16) rc = nl_launch<1, 2>(a, total, tf, bnb, st);
+  else if (d->Cout == 16) rc = nl_launch<2, 1>(a, total, tf, bnb, st);
+  else rc = nl_launch<2, 2>(a, total, tf, bnb, st);
+  if (rc != DT_OK) return rc;
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}

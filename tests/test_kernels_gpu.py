@@ -46,6 +46,10 @@ CONV_CASES = [
     (1, 34, 70, 512, 64, 3, 1, 1),    # many input chunks, width > 2 tiles
     (2, 48, 80, 32, 16, 3, 1, 1),     # dec.4.conv1 shape: 16-wide MFMA kernel, two input chunks
     (1, 24, 40, 8, 12, 3, 1, 1),      # 16-wide kernel with ragged channel counts
+    # round 3: the lean persistent kernel of the narrow layers (conv3x3_f32_narrow_kernel: Cin, Cout in {16, 32}, maps of
+    # at least 8 x 32) — every channel combination, ragged edges, many tiles per persistent workgroup
+    (2, 40, 64, 16, 16, 3, 1, 1), (2, 37, 70, 32, 16, 3, 1, 1), (3, 64, 64, 32, 32, 3, 1, 1), (2, 16, 32, 16, 32, 3, 1, 1),
+    (6, 256, 256, 16, 16, 3, 1, 1), (5, 128, 256, 32, 32, 3, 1, 1),
 ]
 
 
