@@ -496,6 +496,37 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
     if distributed:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt)
+    # roofline of the forward pass: per-launch events of two more (eager, single-stream) batches
+    roof = None
+    if not use_graph and rank == 0:
+        prof = []
+        step()
+        torch.cuda.synchronize()
+        model.engine.profile = prof
+        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        q0.record()
+        for _ in range(2):
+            step()
+        q1.record()
+        torch.cuda.synchronize()
+        model.engine.profile = None
+        ser_s = float(q0.elapsed_time(q1)) * 1e-3 / 2
+        agg, kernels, issued_step, direct_step = roofline_tables(prof, 2, ser_s)
+        convs = {k: v for k, v in agg.items() if kernel_family(k)[1] == "mfma"}
+        if convs:
+            name, (t, fl, n, nb) = max(convs.items(), key=lambda kv: kv[1][0])
+            _, _, issued, kpeak, _ = kernel_family(name)
+            direct = fl / t / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(direct * issued, 2), "peak": kpeak, "unit": "TFLOP/s",
+                    "frac": round(direct * issued / kpeak, 4), "traffic": None, "launches": n,
+                    "avg_launch_ms": round(1e3 * t / n, 4), "share_of_step": round((t / 2) / ser_s, 4),
+                    "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(nb / n),
+                    "measured_on": f"2 eager batches with per-launch events after the timed region ({1e3 * ser_s:.2f} ms per batch)",
+                    "whole_pass_mfma_issued_frac": round(issued_step / (wall / args.steps) / 1e12 / PEAK_FP32_TFLOPS, 4)
+                    if args.precision == "fp32" else None,
+                    "kernels": kernels}
+            if issued != 1.0:
+                roof["direct_equiv_TFLOPs"] = round(direct, 2)
     # PCIe-inclusive rate (never `value`): uint8 tiles from pinned host memory, uint8 class maps back, double-buffered
     # on a copy stream so transfers overlap the previous batch's kernels
     pcie = None
@@ -561,37 +592,6 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
                  "km2_per_hour": round(world * km2_ortho / per_ortho * 3600.0, 1),
                  "what": "uint8 raster H2D + block split + normalise/forward/argmax + block merge on the device + uint8 map D2H, pageable host arrays",
                  "foreground_fraction": round(float(merged.mean()), 4)}
-    # roofline of the forward pass: per-launch events of two more (eager, single-stream) batches
-    roof = None
-    if not use_graph and rank == 0:
-        prof = []
-        step()
-        torch.cuda.synchronize()
-        model.engine.profile = prof
-        q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        q0.record()
-        for _ in range(2):
-            step()
-        q1.record()
-        torch.cuda.synchronize()
-        model.engine.profile = None
-        ser_s = float(q0.elapsed_time(q1)) * 1e-3 / 2
-        agg, kernels, issued_step, direct_step = roofline_tables(prof, 2, ser_s)
-        convs = {k: v for k, v in agg.items() if kernel_family(k)[1] == "mfma"}
-        if convs:
-            name, (t, fl, n, nb) = max(convs.items(), key=lambda kv: kv[1][0])
-            _, _, issued, kpeak, _ = kernel_family(name)
-            direct = fl / t / 1e12
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(direct * issued, 2), "peak": kpeak, "unit": "TFLOP/s",
-                    "frac": round(direct * issued / kpeak, 4), "traffic": None, "launches": n,
-                    "avg_launch_ms": round(1e3 * t / n, 4), "share_of_step": round((t / 2) / ser_s, 4),
-                    "algorithmic_flops_per_launch": round(fl / n), "algorithmic_bytes_per_launch": round(nb / n),
-                    "measured_on": f"2 eager batches with per-launch events after the timed region ({1e3 * ser_s:.2f} ms per batch)",
-                    "whole_pass_mfma_issued_frac": round(issued_step / (wall / args.steps) / 1e12 / PEAK_FP32_TFLOPS, 4)
-                    if args.precision == "fp32" else None,
-                    "kernels": kernels}
-            if issued != 1.0:
-                roof["direct_equiv_TFLOPs"] = round(direct, 2)
     tiles_s = B * world * args.steps / wall
     km2_per_tile = (S * 0.20002 / 1000.0) ** 2          # pixel 0.20002 m (scripts/computestats_inference.py:57-59)
     fwd_flop = 62.59e9 * (S / 512.0) ** 2

@@ -55,6 +55,8 @@ SIGNATURES = {
     "dt_conv2d_winograd": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_winograd_weight_images": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_conv2d_winograd_affine": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "dt_conv2d_narrow_supported": (C.c_int, [_P]),
+    "dt_conv2d_narrow_affine": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_winograd_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),
     "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),
@@ -105,6 +107,9 @@ SIGNATURES = {
     "dt_conv2d_bf16_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_upsample2x_bwd_bn_rows": (C.c_int, [C.c_int] * 4),
     "dt_upsample2x_bwd_bn": (C.c_int, [c_f, c_f, C.POINTER(BnBwdFuse), c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_conv2d_upsampled_dgrad_supported": (C.c_int, [_P]),
+    "dt_conv2d_upsampled_dgrad_rows": (C.c_int, [_P]),
+    "dt_conv2d_upsampled_dgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_upsample2x_bwd_bn_bf16_rows": (C.c_int, [C.c_int] * 4),
     "dt_upsample2x_bwd_bn_bf16": (C.c_int, [c_f, c_f, C.POINTER(BnBwdFuse), c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_stem_s2d_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

@@ -402,7 +402,9 @@ struct NarrowLeanArgs {
 
 #define NL_PIX (N16_HH * N16_HW)   // 340 halo pixels of an 8 x 32 tile
 
-template <int CB, int NB, bool TF, bool BNB>
+// EPI: 0 store (+ BatchNorm statistics); 1 store + fused BatchNorm-backward sums (virtual activation); 4 inference:
+// out = relu(conv * scale + shift) — eval-mode BatchNorm + ReLU on the accumulators (bn_act's mul, add, NaN-keeping ReLU)
+template <int CB, int NB, bool TF, int EPI>
 __global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narrow_kernel(
     const NarrowLeanArgs a, const int total_tiles) {
   constexpr int CIN = 16 * CB, COUT = 16 * NB;
@@ -470,9 +472,11 @@ __global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narro
   for (int nb = 0; nb < NB; ++nb) {
     s1[nb] = s2[nb] = 0.f;
     b_mu[nb] = b_is[nb] = b_sc[nb] = b_sh[nb] = 0.f;
-    if constexpr (BNB) {
+    if constexpr (EPI == 1) {
       b_mu[nb] = a.bnb.mean[16 * nb + m];
       b_is[nb] = a.bnb.invstd[16 * nb + m];
+    }
+    if constexpr (EPI == 1 || EPI == 4) {
       b_sc[nb] = a.bnb.act_scale[16 * nb + m];
       b_sh[nb] = a.bnb.act_shift[16 * nb + m];
     }
@@ -551,13 +555,17 @@ __global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narro
           const size_t o = (((size_t)b * a.Hin + oy) * a.Win + ox) * COUT + m;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
-            const float v = acc[mb][nb][i];
-            if constexpr (BNB) {
+            float v = acc[mb][nb][i];
+            if constexpr (EPI == 4) {
+              v = v * b_sc[nb] + b_sh[nb];
+              v = v < 0.f ? 0.f : v;
+            }
+            if constexpr (EPI == 1) {
               const float yv = a.bnb.y[o + 16 * nb];
               const float g = (yv * b_sc[nb] + b_sh[nb]) > 0.f ? v : 0.f;
               s1[nb] += g;
               s2[nb] += g * ((yv - b_mu[nb]) * b_is[nb]);
-            } else {
+            } else if constexpr (EPI == 0) {
               s1[nb] += v;
               s2[nb] += v * v;
             }
@@ -631,41 +639,555 @@ static int nl_occupancy(K kernel) {
 }
 
 template <int CB, int NB>
-static int nl_launch(const NarrowLeanArgs& a, int total, bool tf, bool bnb, hipStream_t st) {
-  static int occ[3] = {0, 0, 0};
-  const int v = tf ? 1 : (bnb ? 2 : 0);
-  if (occ[v] == 0)
-    occ[v] = tf ? nl_occupancy(conv3x3_f32_narrow_kernel<CB, NB, true, false>)
-                : (bnb ? nl_occupancy(conv3x3_f32_narrow_kernel<CB, NB, false, true>)
-                       : nl_occupancy(conv3x3_f32_narrow_kernel<CB, NB, false, false>));
-  const int grid = total < occ[v] * 256 ? total : occ[v] * 256;
-  const dim3 g((unsigned)grid), blk(256);
-  if (tf) hipLaunchKernelGGL((conv3x3_f32_narrow_kernel<CB, NB, true, false>), g, blk, 0, st, a, total);
-  else if (bnb) hipLaunchKernelGGL((conv3x3_f32_narrow_kernel<CB, NB, false, true>), g, blk, 0, st, a, total);
-  else hipLaunchKernelGGL((conv3x3_f32_narrow_kernel<CB, NB, false, false>), g, blk, 0, st, a, total);
-  return DT_OK;
+static int nl_launch(const NarrowLeanArgs& a, int total, bool tf, int epi, hipStream_t st) {
+  // variants: 0 plain, 1 input transform, 2 BatchNorm-backward sums, 3 inference affine, 4 input transform + affine
+  static int occ[5] = {0, 0, 0, 0, 0};
+  const int v = epi == 1 ? 2 : (epi == 4 ? (tf ? 4 : 3) : (tf ? 1 : 0));
+#define NL_CASE(vv, TFv, EPIv)                                                                              \
+  if (v == vv) {                                                                                            \
+    if (occ[vv] == 0) occ[vv] = nl_occupancy(conv3x3_f32_narrow_kernel<CB, NB, TFv, EPIv>);                   \
+    const int grid = total < occ[vv] * 256 ? total : occ[vv] * 256;                                          \
+    hipLaunchKernelGGL((conv3x3_f32_narrow_kernel<CB, NB, TFv, EPIv>), dim3((unsigned)grid), dim3(256), 0, st, a, total); \
+    return DT_OK;                                                                                           \
+  }
+  NL_CASE(0, false, 0)
+  NL_CASE(1, true, 0)
+  NL_CASE(2, false, 1)
+  NL_CASE(3, false, 4)
+  NL_CASE(4, true, 4)
+#undef NL_CASE
+  return DT_EINVAL;
+}
+
+int dt_conv2d_narrow_launch_upc(const dt_conv_desc* d, const NarrowLeanArgs& a, int total, bool tf, int epi, hipStream_t st);
+
+static bool nl_upc_enabled() {
+  static const int on = [] {
+    const char* e = getenv("DT_FP32_SUBPIXEL");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  return on != 0;
 }
 
 int dt_conv2d_narrow_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
-                            const float* in_scale, const float* in_shift, hipStream_t st, const dt_bn_bwd_fuse* fuse) {
+                            const float* in_scale, const float* in_shift, hipStream_t st, const dt_bn_bwd_fuse* fuse,
+                            bool affine) {
   DT_REQUIRE(dt_conv2d_narrow_supported(d), "conv_narrow: layer shape not supported");
-  const bool tf = in_scale != nullptr, bnb = fuse != nullptr && fuse->y != nullptr;
+  const bool tf = in_scale != nullptr, bnb = !affine && fuse != nullptr && fuse->y != nullptr;
   DT_REQUIRE(!bnb || (fuse->act == nullptr && fuse->act_scale && fuse->act_shift && stats),
              "conv_narrow: the fused BatchNorm-backward sums take a virtual activation and a stats buffer");
   DT_REQUIRE(!(tf && bnb), "conv_narrow: no input transform on the BatchNorm-backward form");
+  DT_REQUIRE(!affine || (fuse && fuse->act_scale && fuse->act_shift && stats == nullptr),
+             "conv_narrow: the inference epilogue needs scale / shift and takes no statistics");
   NarrowLeanArgs a;
   a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.src0 = src0; a.w = w; a.out = out; a.stats = stats; a.in_scale = in_scale; a.in_shift = in_shift;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.mode0 = d->mode0;
   a.tiles_x = dt_cdiv(d->Wo, N16_TW); a.tiles_y = dt_cdiv(d->Ho, N16_TH);
   a.P = dt_conv2d_narrow_rows(d);
-  const int total = nl_tiles(d);
+  const int total = nl_tiles(d), epi = affine ? 4 : (bnb ? 1 : 0);
   int rc;
-  if (d->C0 == 16 && d->Cout == 16) rc = nl_launch<1, 1>(a, total, tf, bnb, st);
-  else if (d->C0 == 16) rc = nl_launch<1, 2>(a, total, tf, bnb, st);
-  else if (d->Cout == 16) rc = nl_launch<2, 1>(a, total, tf, bnb, st);
-  else rc = nl_launch<2, 2>(a, total, tf, bnb, st);
+  if (d->mode0 == 1 && epi != 1 && nl_upc_enabled() && ((d->Hin | d->Win) & 1) == 0 && d->C0 * d->Cout <= 512) {
+    // nearest-upsampled input: the sub-pixel form (4 combined taps per output parity instead of 9); 32 -> 32 would
+    // need 256 weight registers and keeps the 9-tap form
+    rc = dt_conv2d_narrow_launch_upc(d, a, total, tf, epi, st);
+    if (rc != DT_OK) return rc;
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
+  if (d->C0 == 16 && d->Cout == 16) rc = nl_launch<1, 1>(a, total, tf, epi, st);
+  else if (d->C0 == 16) rc = nl_launch<1, 2>(a, total, tf, epi, st);
+  else if (d->Cout == 16) rc = nl_launch<2, 1>(a, total, tf, epi, st);
+  else rc = nl_launch<2, 2>(a, total, tf, epi, st);
   if (rc != DT_OK) return rc;
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+// inference form: out = relu(conv(src) * scale + shift) in ONE launch for the narrow decoder layers — the ATen chain
+// conv2d -> batch_norm(eval) -> relu_ of smp's Conv2dReLU (deadtrees/network/extra/modules.py:74-92 twin); same
+// arithmetic as dt_conv2d followed by dt_bn_act (bit-identical), the raw output is never stored
+extern "C" int dt_conv2d_narrow_affine(const dt_conv_desc* d, const float* src0, const float* w_hwio, float* out,
+                                       const float* scale, const float* shift, const float* in_scale,
+                                       const float* in_shift, void* stream) {
+  DT_REQUIRE(d && src0 && w_hwio && out && scale && shift, "conv_narrow_affine: null pointer");
+  DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv_narrow_affine: in_scale/in_shift must come together");
+  dt_bn_bwd_fuse f{nullptr, nullptr, nullptr, scale, shift, nullptr};
+  return dt_conv2d_narrow_launch(d, src0, w_hwio, out, nullptr, in_scale, in_shift, (hipStream_t)stream, &f, true);
+}
+
+// ================================================================================================================
+// Round 3: the same layers when the input is NEAREST-UPSAMPLED (mode0 = 1: dec4.conv1, 32 -> 16 over up(dec3)) — the
+// "sub-pixel" form.  A 3x3 convolution over an image in which every 2x2 block repeats one source pixel reads only 2x2
+// DISTINCT source pixels per output pixel: for output parity (a, b) = (row & 1, column & 1)
+//     y[2Y + a][2X + b] = sum_{dy, dx in {0,1}} W'_ab[dy][dx] . x[Y + a - 1 + dy][X + b - 1 + dx],
+//     W'_ab[dy][dx] = sum_{kh in R(a,dy)} sum_{kw in R(b,dx)} W[kh][kw],   R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}
+// — 4 taps instead of 9: 2.25x fewer multiplies on a layer that is MFMA-bound in fp32 (exact algebra, zero padding
+// included: an out-of-range source pixel is exactly the padding of the up-sampled image; the pre-summed weights round
+// once more, ~1e-7 relative).  The 16 combined matrices live in registers (64 CB NB of them); a workgroup's 8 x 32
+// output tile comes from a 6 x 18 LOW-RESOLUTION halo (17 KB of LDS instead of 54); an M block = 16 output pixels of
+// one parity in one output row, so the 16 (parity, tap) products of a source row need only 9 distinct fragment reads.
+template <int CB, int NB, bool TF, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_f32_upc_kernel(const NarrowLeanArgs a, const int total_tiles) {
+  constexpr int CIN = 16 * CB, COUT = 16 * NB;
+  constexpr int PITCH = CB == 1 ? 96 : 160;
+  constexpr int SLOTS = 4 * CB;
+  constexpr int LH = N16_TH / 2 + 2, LW = N16_TW / 2 + 2, LPIX = LH * LW;   // 6 x 18 low-resolution halo pixels
+  constexpr int FILL = (LPIX * SLOTS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LPIX * PITCH > 4096 ? LPIX * PITCH : 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  const int Hs = a.Hin >> 1, Ws = a.Win >> 1;
+  const int NG = gridDim.x;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + NG - 1) / NG;
+  auto tile_of = [&](int round) { return (int)xcd_remap(blockIdx.x + (unsigned)round * NG, (unsigned)total_tiles); };
+
+  // ---- combined weights -> registers: wc[a][dy][b][dx][cb][j][nb], built from the lane's 9 original taps
+  float wc[2][2][2][2][CB][4][NB];
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        float w9[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[t / 3][t % 3] = a.w[((size_t)t * CIN + 16 * cb + 4 * kq + j) * COUT + 16 * nb + m];
+        // rows first: R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}
+        float rw[2][2][3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          rw[0][0][kw] = w9[0][kw];
+          rw[0][1][kw] = w9[1][kw] + w9[2][kw];
+          rw[1][0][kw] = w9[0][kw] + w9[1][kw];
+          rw[1][1][kw] = w9[2][kw];
+        }
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            wc[pa][dy][0][0][cb][j][nb] = rw[pa][dy][0];
+            wc[pa][dy][0][1][cb][j][nb] = rw[pa][dy][1] + rw[pa][dy][2];
+            wc[pa][dy][1][0][cb][j][nb] = rw[pa][dy][0] + rw[pa][dy][1];
+            wc[pa][dy][1][1][cb][j][nb] = rw[pa][dy][2];
+          }
+      }
+
+  // wave w = low-resolution row Y = w of the tile; fragment (r, c): halo pixel (w + r, m + c), slot kq of block cb
+  const int abase = (wave * LW + m) * PITCH + 16 * kq;
+  const int f_pix0 = tid / SLOTS, f_slot = tid % SLOTS, f_ch = 4 * f_slot;
+  f32x4 tf_sc = {1.f, 1.f, 1.f, 1.f}, tf_sh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (TF) {
+    tf_sc = *reinterpret_cast<const f32x4*>(a.in_scale + f_ch);
+    tf_sh = *reinterpret_cast<const f32x4*>(a.in_shift + f_ch);
+  }
+  f32x4 rin[FILL];
+  unsigned rvalid = 0;
+  auto issue_loads = [&](int round) {
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int y0 = ty * (N16_TH / 2) - 1, x0 = tx * (N16_TW / 2) - 1;
+    rvalid = 0;
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int pix = f_pix0 + it * (256 / SLOTS);
+      const int hy = pix / LW, hx = pix - hy * LW;
+      const int sy = y0 + hy, sx = x0 + hx;
+      const bool ok = pix < LPIX && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.src0 + ((size_t)(b * Hs + sy) * Ws + sx) * CIN + f_ch);
+      rvalid |= (ok ? 1u : 0u) << it;
+      rin[it] = v;
+    }
+  };
+  float s1[NB], s2[NB], b_sc[NB], b_sh[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    s1[nb] = s2[nb] = 0.f;
+    b_sc[nb] = b_sh[nb] = 0.f;
+    if constexpr (EPI == 4) {
+      b_sc[nb] = a.bnb.act_scale[16 * nb + m];
+      b_sh[nb] = a.bnb.act_shift[16 * nb + m];
+    }
+  }
+  const bool want_stats = a.stats != nullptr;
+
+  if (my_tiles > 0) issue_loads(0);
+  for (int round = 0; round < my_tiles; ++round) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int pix = f_pix0 + it * (256 / SLOTS);
+      if (pix < LPIX) {
+        f32x4 v = rin[it];
+        if constexpr (TF) {
+          if ((rvalid >> it) & 1u) {
+            v = v * tf_sc + tf_sh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+          }
+        }
+        *reinterpret_cast<f32x4*>(lds + pix * PITCH + 16 * f_slot) = v;
+      }
+    }
+    __syncthreads();
+    if (round + 1 < my_tiles) issue_loads(round + 1);
+
+    f32x4 acc[2][2][NB];   // [row parity a][column parity b]
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[pa][pb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragments f = (cb, r, c), one ahead in registers; fragment (r, c) serves every (a, dy) with a + dy = r and every
+    // (b, dx) with b + dx = c.  Taps in (dy, dx) order per parity = kh -> kw order of the direct form.
+    auto frag = [&](int f) -> f32x4 {
+      const int cb = f / 9, r = (f % 9) / 3, c = f % 3;
+      return *reinterpret_cast<const f32x4*>(lds + abase + (r * LW + c) * PITCH + 64 * cb);
+    };
+    f32x4 fav[2];
+    fav[0] = frag(0);
+#pragma unroll
+    for (int f = 0; f < 9 * CB; ++f) {
+      if (f + 1 < 9 * CB) fav[(f + 1) & 1] = frag(f + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cb = f / 9, r = (f % 9) / 3, c = f % 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const int dy = r - pa, dx = c - pb;
+            if (dy >= 0 && dy < 2 && dx >= 0 && dx < 2) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[pa][pb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fav[f & 1][j], wc[pa][dy][pb][dx][cb][j][nb],
+                                                                       acc[pa][pb][nb], 0, 0, 0);
+            }
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: M block (a, b): output row 2 w + a, columns 2 (4 kq + i) + b of the tile
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * N16_TH, ox0 = tx * N16_TW;
+    const bool interior = oy0 + N16_TH <= a.Hin && ox0 + N16_TW <= a.Win;
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa) {
+      const int oy = oy0 + 2 * wave + pa;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ox = ox0 + 2 * (4 * kq + i) + pb;
+          if (interior || (oy < a.Hin && ox < a.Win)) {
+            const size_t o = (((size_t)b * a.Hin + oy) * a.Win + ox) * COUT + m;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              float v = acc[pa][pb][nb][i];
+              if constexpr (EPI == 4) {
+                v = v * b_sc[nb] + b_sh[nb];
+                v = v < 0.f ? 0.f : v;
+              } else {
+                s1[nb] += v;
+                s2[nb] += v * v;
+              }
+              a.out[o + 16 * nb] = v;
+            }
+          }
+        }
+    }
+  }
+  if (want_stats) {
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float u1 = s1[nb], u2 = s2[nb];
+      u1 += __shfl_xor(u1, 16, 64);
+      u2 += __shfl_xor(u2, 16, 64);
+      u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 32, 64);
+      if (kq == 0) {
+        red[(wave * NB + nb) * 16 + m] = u1;
+        red[512 + (wave * NB + nb) * 16 + m] = u2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      const int which = tid / COUT, c = tid % COUT, nb = c >> 4, n = c & 15;
+      const float* r = red + which * 512 + nb * 16 + n;
+      a.stats[((size_t)which * a.P + blockIdx.x) * COUT + c] = (r[0] + r[NB * 16]) + (r[2 * NB * 16] + r[3 * NB * 16]);
+      for (int q = (int)blockIdx.x + NG; q < a.P; q += NG) a.stats[((size_t)which * a.P + q) * COUT + c] = 0.f;
+    }
+  }
+}
+
+// the sub-pixel form serves the up-sampled layers without fused BatchNorm-backward sums (forward / inference of dec4.conv1)
+template <int CB, int NB>
+static int nl_launch_upc(const NarrowLeanArgs& a, int total, bool tf, int epi, hipStream_t st) {
+  static int occ[4] = {0, 0, 0, 0};
+  const int v = (epi == 4 ? 2 : 0) + (tf ? 1 : 0);
+#define NLU_CASE(vv, TFv, EPIv)                                                                          \
+  if (v == vv) {                                                                                         \
+    if (occ[vv] == 0) occ[vv] = nl_occupancy(conv3x3_f32_upc_kernel<CB, NB, TFv, EPIv>);                   \
+    const int grid = total < occ[vv] * 256 ? total : occ[vv] * 256;                                       \
+    hipLaunchKernelGGL((conv3x3_f32_upc_kernel<CB, NB, TFv, EPIv>), dim3((unsigned)grid), dim3(256), 0, st, a, total); \
+    return DT_OK;                                                                                        \
+  }
+  NLU_CASE(0, false, 0)
+  NLU_CASE(1, true, 0)
+  NLU_CASE(2, false, 4)
+  NLU_CASE(3, true, 4)
+#undef NLU_CASE
+  return DT_EINVAL;
+}
+
+int dt_conv2d_narrow_launch_upc(const dt_conv_desc* d, const NarrowLeanArgs& a, int total, bool tf, int epi, hipStream_t st) {
+  if (d->C0 == 16 && d->Cout == 16) return nl_launch_upc<1, 1>(a, total, tf, epi, st);
+  if (d->C0 == 16) return nl_launch_upc<1, 2>(a, total, tf, epi, st);
+  if (d->Cout == 16) return nl_launch_upc<2, 1>(a, total, tf, epi, st);
+  return nl_launch_upc<2, 2>(a, total, tf, epi, st);
+}
+
+// ================================================================================================================
+// Data gradient of the same up-sampled layer, sub-pixel form: the transpose of conv3x3_f32_upc_kernel.  The reference
+// chain convolution_backward(input) of the 3x3 convolution at full resolution (9 taps x 4 pixels per source pixel)
+// followed by the backward of F.interpolate(nearest, x2) (a 2x2 sum) collapses into ONE 4x4 stride-2 convolution over
+// dY with 16 combined weight matrices:
+//     g[Y][X] = sum_{r, c = 0..3} V[r][c] . dY[2Y - 1 + r][2X - 1 + c],   V[r][c] = W'_{a(r) b(c)}[dy(r)][dx(c)]^T,
+//     r = 3 - a - 2 dy  (r = 0: (a, dy) = (1, 1); 1: (0, 1); 2: (1, 0); 3: (0, 0)), columns alike
+// — 16 tap products per source pixel instead of 36, and the full-resolution gradient of the up-sampled tensor
+// (32 channels at 512x512: 1 GB written and read back per 32-tile step) never exists.  The BatchNorm-backward sums of
+// the layer the gradient belongs to (what dt_upsample2x_bwd_bn fused into the 2x2-sum pass) ride in the epilogue.
+// dY tile in LDS split by column parity ([row][parity][17 columns]) so that the stride-2 fragment reads are unit-stride.
+struct UpcDgradArgs {
+  const float* dy;     // [B][H][W][CO] gradient of the convolution's output (full resolution)
+  const float* w;      // [9][CI][CO] the FORWARD weights (HWIO)
+  float* gx;           // [B][H/2][W/2][CI] gradient of the low-resolution input
+  float* stats;        // [2][P][CI] fused BatchNorm-backward sums, or null
+  dt_bn_bwd_fuse bnb;
+  int B, H, W, tiles_x, tiles_y, P;
+};
+
+template <int CIB /* CI / 16 */, int COB /* CO / 16 */, bool BNB>
+__global__ __launch_bounds__(256, 2) void conv3x3_f32_upc_dgrad_kernel(const UpcDgradArgs a, const int total_tiles) {
+  constexpr int CI = 16 * CIB, CO = 16 * COB;
+  constexpr int PITCH = COB == 1 ? 96 : 160;
+  constexpr int SLOTS = 4 * COB;
+  constexpr int TR = 10, TC = 34, HC = 17;                 // dY tile: 10 rows x 34 columns = [row][parity][17]
+  constexpr int TPIX = TR * TC;
+  constexpr int FILL = (TPIX * SLOTS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TPIX * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  const int Hs = a.H >> 1, Ws = a.W >> 1;
+  const int NG = gridDim.x;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + NG - 1) / NG;
+  auto tile_of = [&](int round) { return (int)xcd_remap(blockIdx.x + (unsigned)round * NG, (unsigned)total_tiles); };
+
+  // ---- V[r][c] -> registers: B operand of K step (r, c, block cob, j): B[k = kq][n] = V[r][c][co = 16 cob + 4 kq + j][ci = 16 nb + m]
+  float vreg[4][4][COB][4][CIB];
+#pragma unroll
+  for (int cob = 0; cob < COB; ++cob)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < CIB; ++nb) {
+        float w9[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[t / 3][t % 3] = a.w[((size_t)t * CI + 16 * nb + m) * CO + 16 * cob + 4 * kq + j];
+        // row classes r = 0..3 <-> (a, dy) = (1,1), (0,1), (1,0), (0,0) <-> tap rows {2}, {1,2}, {0,1}, {0}
+        float rw[4][3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          rw[0][kw] = w9[2][kw];
+          rw[1][kw] = w9[1][kw] + w9[2][kw];
+          rw[2][kw] = w9[0][kw] + w9[1][kw];
+          rw[3][kw] = w9[0][kw];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vreg[r][0][cob][j][nb] = rw[r][2];
+          vreg[r][1][cob][j][nb] = rw[r][1] + rw[r][2];
+          vreg[r][2][cob][j][nb] = rw[r][0] + rw[r][1];
+          vreg[r][3][cob][j][nb] = rw[r][0];
+        }
+      }
+
+  // wave w = low-resolution row w of the 4 x 16 tile; tap (r, c): dY row 2 w + r, column 2 m + c of the tile
+  const int abase = ((2 * wave) * 2 * HC + m) * PITCH + 16 * kq;
+  const int f_pix0 = tid / SLOTS, f_slot = tid % SLOTS, f_ch = 4 * f_slot;
+  f32x4 rin[FILL];
+  auto issue_loads = [&](int round) {
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int y0 = 8 * ty - 1, x0 = 32 * tx - 1;
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int pix = f_pix0 + it * (256 / SLOTS);          // linear (row, column) index of the tile
+      const int hy = pix / TC, hx = pix - hy * TC;
+      const int oy = y0 + hy, ox = x0 + hx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < TPIX && (unsigned)oy < (unsigned)a.H && (unsigned)ox < (unsigned)a.W)
+        v = *reinterpret_cast<const f32x4*>(a.dy + ((size_t)(b * a.H + oy) * a.W + ox) * CO + f_ch);
+      rin[it] = v;
+    }
+  };
+  float s1[CIB], s2[CIB], b_mu[CIB], b_is[CIB], b_sc[CIB], b_sh[CIB];
+#pragma unroll
+  for (int nb = 0; nb < CIB; ++nb) {
+    s1[nb] = s2[nb] = b_mu[nb] = b_is[nb] = b_sc[nb] = b_sh[nb] = 0.f;
+    if constexpr (BNB) {
+      b_mu[nb] = a.bnb.mean[16 * nb + m];
+      b_is[nb] = a.bnb.invstd[16 * nb + m];
+      b_sc[nb] = a.bnb.act_scale[16 * nb + m];
+      b_sh[nb] = a.bnb.act_shift[16 * nb + m];
+    }
+  }
+
+  if (my_tiles > 0) issue_loads(0);
+  for (int round = 0; round < my_tiles; ++round) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FILL; ++it) {
+      const int pix = f_pix0 + it * (256 / SLOTS);
+      if (pix < TPIX) {
+        const int hy = pix / TC, hx = pix - hy * TC;
+        *reinterpret_cast<f32x4*>(lds + ((hy * 2 + (hx & 1)) * HC + (hx >> 1)) * PITCH + 16 * f_slot) = rin[it];
+      }
+    }
+    __syncthreads();
+    if (round + 1 < my_tiles) issue_loads(round + 1);
+
+    f32x4 acc[CIB];
+#pragma unroll
+    for (int nb = 0; nb < CIB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto frag = [&](int f) -> f32x4 {
+      const int cob = f / 16, r = (f % 16) / 4, c = f % 4;
+      return *reinterpret_cast<const f32x4*>(lds + abase + ((r * 2 + (c & 1)) * HC + (c >> 1)) * PITCH + 64 * cob);
+    };
+    f32x4 fav[2];
+    fav[0] = frag(0);
+#pragma unroll
+    for (int f = 0; f < 16 * COB; ++f) {
+      if (f + 1 < 16 * COB) fav[(f + 1) & 1] = frag(f + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int cob = f / 16, r = (f % 16) / 4, c = f % 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < CIB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fav[f & 1][j], vreg[r][c][cob][j][nb], acc[nb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: low-resolution pixel (4 ty + w, 16 tx + 4 kq + i), channel 16 nb + m
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int Y = 4 * ty + wave;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int X = 16 * tx + 4 * kq + i;
+      if (Y < Hs && X < Ws) {
+        const size_t o = (((size_t)b * Hs + Y) * Ws + X) * CI + m;
+#pragma unroll
+        for (int nb = 0; nb < CIB; ++nb) {
+          const float v = acc[nb][i];
+          if constexpr (BNB) {
+            const float yv = a.bnb.y[o + 16 * nb];
+            const float g = (yv * b_sc[nb] + b_sh[nb]) > 0.f ? v : 0.f;
+            s1[nb] += g;
+            s2[nb] += g * ((yv - b_mu[nb]) * b_is[nb]);
+          }
+          a.gx[o + 16 * nb] = v;
+        }
+      }
+    }
+  }
+  if (BNB && a.stats != nullptr) {
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < CIB; ++nb) {
+      float u1 = s1[nb], u2 = s2[nb];
+      u1 += __shfl_xor(u1, 16, 64);
+      u2 += __shfl_xor(u2, 16, 64);
+      u1 += __shfl_xor(u1, 32, 64);
+      u2 += __shfl_xor(u2, 32, 64);
+      if (kq == 0) {
+        red[(wave * CIB + nb) * 16 + m] = u1;
+        red[512 + (wave * CIB + nb) * 16 + m] = u2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * CI) {
+      const int which = tid / CI, c = tid % CI, nb = c >> 4, n = c & 15;
+      const float* r = red + which * 512 + nb * 16 + n;
+      a.stats[((size_t)which * a.P + blockIdx.x) * CI + c] = (r[0] + r[CIB * 16]) + (r[2 * CIB * 16] + r[3 * CIB * 16]);
+      for (int q = (int)blockIdx.x + NG; q < a.P; q += NG) a.stats[((size_t)which * a.P + q) * CI + c] = 0.f;
+    }
+  }
+}
+
+// `d` describes the FORWARD convolution (mode0 = 1, C0 = CI low-resolution input channels, Cout = CO, Hin x Win = the
+// full-resolution map)
+extern "C" int dt_conv2d_upsampled_dgrad_supported(const dt_conv_desc* d) {
+  if (!nl_enabled() || !nl_upc_enabled() || d == nullptr) return 0;
+  if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->mode0 != 1 || d->C1 != 0 || d->cout_split != 0) return 0;
+  if ((d->C0 != 16 && d->C0 != 32) || (d->Cout != 16 && d->Cout != 32) || d->C0 * d->Cout > 512) return 0;
+  if (((d->Hin | d->Win) & 1) != 0 || d->Ho != d->Hin || d->Wo != d->Win || d->Win < 32 || d->Hin < 8) return 0;
+  return 1;
+}
+
+static int upcd_tiles(const dt_conv_desc* d) { return d->B * dt_cdiv(d->Hin / 2, 4) * dt_cdiv(d->Win / 2, 16); }
+
+extern "C" int dt_conv2d_upsampled_dgrad_rows(const dt_conv_desc* d) {
+  if (!dt_conv2d_upsampled_dgrad_supported(d)) return 0;
+  const int t = upcd_tiles(d);
+  return t < 8 * 256 ? t : 8 * 256;
+}
+
+template <int CIB, int COB>
+static int upcd_launch(const UpcDgradArgs& a, int total, bool bnb, hipStream_t st) {
+  static int occ[2] = {0, 0};
+  if (bnb) {
+    if (occ[1] == 0) occ[1] = nl_occupancy(conv3x3_f32_upc_dgrad_kernel<CIB, COB, true>);
+    const int grid = total < occ[1] * 256 ? total : occ[1] * 256;
+    hipLaunchKernelGGL((conv3x3_f32_upc_dgrad_kernel<CIB, COB, true>), dim3((unsigned)grid), dim3(256), 0, st, a, total);
+  } else {
+    if (occ[0] == 0) occ[0] = nl_occupancy(conv3x3_f32_upc_dgrad_kernel<CIB, COB, false>);
+    const int grid = total < occ[0] * 256 ? total : occ[0] * 256;
+    hipLaunchKernelGGL((conv3x3_f32_upc_dgrad_kernel<CIB, COB, false>), dim3((unsigned)grid), dim3(256), 0, st, a, total);
+  }
+  return DT_OK;
+}
+
+// gx = d loss / d x for y = conv3x3(nearest_upsample_x2(x)): replaces dt_conv2d (data-gradient form) + dt_upsample2x_bwd
+// (_bn) of the generic chain; red (with fuse) receives the BatchNorm-backward sums like dt_upsample2x_bwd_bn
+extern "C" int dt_conv2d_upsampled_dgrad(const dt_conv_desc* d, const float* dy, const float* w_hwio, float* gx, float* red,
+                                         const dt_bn_bwd_fuse* fuse, void* stream) {
+  DT_REQUIRE(d && dy && w_hwio && gx, "conv_upsampled_dgrad: null pointer");
+  DT_REQUIRE(dt_conv2d_upsampled_dgrad_supported(d), "conv_upsampled_dgrad: layer shape not supported");
+  const bool bnb = fuse != nullptr && fuse->y != nullptr;
+  DT_REQUIRE(!bnb || (red && fuse->mean && fuse->invstd && fuse->act_scale && fuse->act_shift),
+             "conv_upsampled_dgrad: the fused sums need red, mean, invstd and the activation's scale / shift");
+  UpcDgradArgs a;
+  a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  a.dy = dy; a.w = w_hwio; a.gx = gx; a.stats = bnb ? red : nullptr;
+  a.B = d->B; a.H = d->Hin; a.W = d->Win;
+  a.tiles_x = dt_cdiv(d->Win / 2, 16); a.tiles_y = dt_cdiv(d->Hin / 2, 4);
+  a.P = dt_conv2d_upsampled_dgrad_rows(d);
+  const int total = upcd_tiles(d);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->C0 == 16 && d->Cout == 16) upcd_launch<1, 1>(a, total, bnb, st);
+  else if (d->C0 == 32 && d->Cout == 16) upcd_launch<2, 1>(a, total, bnb, st);
+  else upcd_launch<1, 2>(a, total, bnb, st);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

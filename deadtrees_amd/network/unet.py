@@ -308,7 +308,7 @@ class UNetEngine:
         self._pe(e0, "bn_act_kernel", 0.0, 4.0 * y.numel() * (2 + (res is not None)))
         return z
 
-    def _conv_affine_eval(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, res=None):
+    def _conv_affine_eval(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, res=None, in_ss=None):
         """inference: relu(bn_eval(conv(x)) [+ res]) in ONE Winograd launch (dt_conv2d_winograd_affine) — no raw output, no
         bn_act pass.  Returns the activation, or None when the layer is not a Winograd layer (caller: conv + bn_act)."""
         if not self._fuse_eval or c.k != 3 or c.stride != 1 or c.pad != 1:
@@ -317,7 +317,8 @@ class UNetEngine:
         C1 = 0 if src1 is None else src1.shape[-1]
         desc = self._desc(B, Hin, Win, C0, C1, mode0, Hin, Win, c.cout, 3, 1, 1)
         u = self._u(c)
-        if not self._use_wino(desc, u):
+        narrow = res is None and not self._use_wino(desc, u) and bool(self.lib.dt_conv2d_narrow_supported(C.byref(desc)))
+        if not narrow and (in_ss is not None or not self._use_wino(desc, u)):
             return None
         scale, shift = self._ss(c, bnws)
         if not self._affine_fresh:
@@ -327,6 +328,14 @@ class UNetEngine:
                                                   c.cout, _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
         z = torch.empty((B, Hin, Win, c.cout), dtype=torch.float32, device=src0.device)
         e0 = self._pb()
+        if narrow:     # the narrow decoder layers (dec3.conv2, dec4): the lean kernel's inference epilogue
+            _lib.check(self.lib.dt_conv2d_narrow_affine(C.byref(desc), _p(src0), _p(params[c.w_off:c.w_off + c.w_size]), _p(z),
+                                                        _p(scale), _p(shift), _p(in_ss[0]) if in_ss else None,
+                                                        _p(in_ss[1]) if in_ss else None, _stream()), "dt_conv2d_narrow_affine")
+            if e0 is not None:
+                fl, nb = self._conv_work(desc)
+                self._pe(e0, f"conv3x3_f32_narrow_kernel<{C0 // 16}, {c.cout // 16}, {'true' if in_ss else 'false'}, 4>", fl, nb)
+            return z
         _lib.check(self.lib.dt_conv2d_winograd_affine(C.byref(desc), _p(src0), _p(src1), _p(u), _p(z), _p(scale),
                                                       _p(shift), _p(res), _stream()), "dt_conv2d_winograd_affine")
         if e0 is not None:
@@ -464,7 +473,16 @@ class UNetEngine:
                 continue
             if self._fuse_eval and d_ss is None:
                 z1 = self._conv_affine_eval(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win)
-                z2 = None if z1 is None else self._conv_affine_eval(blk.conv2, params, bnstate, bnws, z1, None, 0, B, Hin, Win)
+                if z1 is not None:
+                    z2 = self._conv_affine_eval(blk.conv2, params, bnstate, bnws, z1, None, 0, B, Hin, Win)
+                else:
+                    # conv1 is neither a Winograd nor a narrow layer (dec3.conv1: 128 -> 32 from two sources): its raw output
+                    # feeds conv2's lean kernel, which applies bn1 + ReLU while staging AND bn2 + ReLU in its epilogue
+                    y1, _, _, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, d, skip, 1, B, Hin, Win, training)
+                    z2 = self._conv_affine_eval(blk.conv2, params, bnstate, bnws, y1, None, 0, B, Hin, Win, in_ss=ss1)
+                    if z2 is None:
+                        z2 = self._bn_act(self._conv_bn(blk.conv2, params, bnstate, bnws, y1, None, 0, B, Hin, Win, training,
+                                                        in_ss=ss1)[0], self._ss(blk.conv2, bnws))
                 if z2 is not None:
                     d, dh, dw, d_ss = z2, Hin, Win, None
                     continue
@@ -1282,6 +1300,32 @@ class UNetEngine:
             prof.append((name, flops, e0, e1, nbytes))
         return red, P
 
+    def _upsampled_dgrad(self, blk, prev_conv: ConvSpec, params, bnws, dy1, y2p, d, B, Hh, Ww) -> bool:
+        """decoder block without a skip: gradient of the block input (low resolution) straight from dy1 — the data
+        gradient of conv1 and the backward of the nearest x2 upsample in one sub-pixel kernel, the BatchNorm-backward
+        sums of the previous block's conv2 in its epilogue.  Fills d["g"], d["g_red"]; False where the layer shape is
+        not covered (the generic chain runs)."""
+        c = blk.conv1
+        cx = blk.in_ch
+        desc = self._desc(B, Hh, Ww, cx, 0, 1, Hh, Ww, c.cout, c.k, c.stride, c.pad, 0, 0)
+        if not self.lib.dt_conv2d_upsampled_dgrad_supported(C.byref(desc)):
+            return False
+        lib = self.lib
+        P = lib.dt_conv2d_upsampled_dgrad_rows(C.byref(desc))
+        red = self._buf("bn_red_up", lib.dt_bn_stats_floats(P, cx), device=dy1.device)
+        psc, psh = self._ss(prev_conv, bnws)
+        nbq = self.spec.n_bn_channels
+        fuse = _lib.BnBwdFuse(_p(y2p), _p(bnws[prev_conv.bn_off: prev_conv.bn_off + cx]),
+                              _p(bnws[nbq + prev_conv.bn_off: nbq + prev_conv.bn_off + cx]), _p(psc), _p(psh))
+        g = torch.empty_like(d["x"])
+        ev = self._pb()
+        _lib.check(lib.dt_conv2d_upsampled_dgrad(C.byref(desc), _p(dy1), _p(params[c.w_off:c.w_off + c.w_size]), _p(g),
+                                                 _p(red), C.byref(fuse), _stream()), "dt_conv2d_upsampled_dgrad")
+        self._pe(ev, "conv3x3_f32_upc_dgrad_kernel", 2.0 * 9 * cx * c.cout * Hh * Ww * B,
+                 4.0 * B * Hh * Ww * c.cout + 4.0 * B * (Hh // 2) * (Ww // 2) * cx * 2)
+        d["g"], d["g_red"] = g, (red, P)
+        return True
+
     def _dgrad(self, c: ConvSpec, params, dy, B, Hin, Win, out0, out1=None, split=0, acc=False):
         """gradient wrt the conv's logical input [B,Hin,Win,cin] (before virtual upsample handling)."""
         Ho, Wo = dy.shape[1], dy.shape[2]
@@ -1466,6 +1510,12 @@ class UNetEngine:
             x_ss = self._ss(sp.decoder[i - 1].conv2, bnws) if d["x_virtual"] else None
             self._wgrad(blk.conv1, grads, d["x"], d["skip"], 1, B, Hh, Ww, dy1, in_ss=x_ss)
             cx = blk.in_ch
+            if d["skip"] is None and i >= 1 and self._fuse_bn and self._upsampled_dgrad(blk, sp.decoder[i - 1].conv2, params,
+                                                                                       bnws, dy1, S[f"D{i - 1}"]["y2"], d, B, Hh, Ww):
+                g, g_red = d["g"], d["g_red"]
+                del dy1
+                S[f"D{i}"] = None
+                continue
             dup = torch.empty((B, Hh, Ww, cx), dtype=torch.float32, device=dev)
             if d["skip"] is not None:
                 dskip = torch.empty_like(d["skip"])

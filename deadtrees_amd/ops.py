@@ -450,6 +450,28 @@ def upsample2x_bwd_bn(dup, y, mean, invstd, act_scale, act_shift):
     return dx, red[:2 * P * Cc].view(2, P, Cc)
 
 
+def conv2d_upsampled_dgrad(dy, w_hwio, cin, y=None, mean=None, invstd=None, act_scale=None, act_shift=None):
+    """gradient of x for out = conv3x3(nearest_upsample_x2(x)) (pad 1) from dy [B,2h,2w,cout] and the forward weights
+    [3,3,cin,cout] in one sub-pixel kernel -> (gx [B,h,w,cin], red [2,P,cin] or None).  With y/mean/invstd/act_*: the
+    BatchNorm-backward partial sums of the layer with raw output y (x = relu(y*act_scale+act_shift)) come along."""
+    _gpu(dy, w_hwio)
+    lib = _lib.load()
+    B, H, W, cout = dy.shape
+    d = _lib.ConvDesc(B, H, W, cin, 0, 1, H, W, cout, 3, 1, 1, 0, 0)
+    if not lib.dt_conv2d_upsampled_dgrad_supported(C.byref(d)):
+        raise ValueError("conv2d_upsampled_dgrad: layer shape not covered by the sub-pixel kernel")
+    gx = torch.empty((B, H // 2, W // 2, cin), dtype=torch.float32, device=dy.device)
+    red, fuse, P = None, None, 0
+    if y is not None:
+        _gpu(y, mean, invstd, act_scale, act_shift)
+        P = lib.dt_conv2d_upsampled_dgrad_rows(C.byref(d))
+        red = torch.empty(lib.dt_bn_stats_floats(P, cin), dtype=torch.float32, device=dy.device)
+        fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift))
+    _lib.check(lib.dt_conv2d_upsampled_dgrad(C.byref(d), _p(dy.contiguous()), _p(w_hwio.contiguous()), _p(gx), _p(red),
+                                             C.byref(fuse) if fuse is not None else None, _st()), "dt_conv2d_upsampled_dgrad")
+    return gx, (red[:2 * P * cin].view(2, P, cin) if red is not None else None)
+
+
 def stem_conv_bf16(x_nhwc_f32, w_hwio_7x7, want_stats=False):
     """the 7x7 / stride-2 / pad-3 stem on the bf16 MFMA kernels: fp32 NHWC image [B,H,W,Cin<=4] -> bf16
     [B,H/2,W/2,Cout] (+ fp32 BatchNorm partial statistics), via the 2x2 space-to-depth image and a 4x4 window"""

@@ -92,6 +92,12 @@ int dt_conv2d_winograd(const dt_conv_desc* d, const float* src0, const float* sr
  * arithmetic as dt_conv2d_winograd followed by dt_bn_act: bit-identical.  No split outputs, joins or statistics. */
 int dt_conv2d_winograd_affine(const dt_conv_desc* d, const float* src0, const float* src1, const float* u, float* out,
                               const float* scale, const float* shift, const float* residual, void* stream);
+/* The same one-launch inference form for the narrow full-resolution decoder layers (3x3 stride 1 pad 1, Cin and Cout in
+ * {16, 32}, maps of at least 8 x 32 pixels; dt_conv2d_narrow_supported tells): out = relu(conv(x) * scale + shift), with
+ * x = src0 or — in_scale / in_shift given — relu(src0 * in_scale + in_shift) (the producer's virtual activation). */
+int dt_conv2d_narrow_supported(const dt_conv_desc* d);
+int dt_conv2d_narrow_affine(const dt_conv_desc* d, const float* src0, const float* w_hwio, float* out, const float* scale,
+                            const float* shift, const float* in_scale, const float* in_shift, void* stream);
 /* all eligible layers in one launch: int32 table rows (w_off, u_off, Cin, Cout, first_block), blocks of a layer =
  * ceil(Cout/64) * ceil(Cin/16); `weights` = the flat parameter buffer (forward images) or its dt_weight_images mode-0
  * image with Cin/Cout swapped (data-gradient images). */
@@ -400,6 +406,18 @@ int dt_conv2d_bf16_bn_bwd(const dt_conv_desc* desc, const void* src0, const void
 int dt_upsample2x_bwd_bn_rows(int B, int H, int W, int C);
 int dt_upsample2x_bwd_bn(const float* dup, float* dx, const dt_bn_bwd_fuse* fuse, float* red, int B, int H, int W, int C,
                          void* stream);
+/* Data gradient of y = conv3x3(nearest_upsample_x2(x)) in ONE kernel (sub-pixel form: a 4x4 stride-2 convolution over
+ * dY with 16 combined weight matrices, 16 tap products per source pixel instead of 36): replaces the chain
+ * dt_conv2d (data-gradient form) -> dt_upsample2x_bwd(_bn) for the narrow decoder layer without a skip (reference:
+ * autograd of F.interpolate(x, scale_factor=2, mode="nearest") + Conv2d, deadtrees/network/segmodel.py:30-57 via
+ * segmentation_models_pytorch 0.2.1 unet/decoder.py DecoderBlock.forward).  `desc` describes the FORWARD convolution
+ * (mode0 = 1, C0 = channels of x, Cout); w_hwio the forward weights; gx[B, Hin/2, Win/2, C0].  With `fuse` (y, mean,
+ * invstd, act_scale, act_shift of the layer that produced x) red[2][P][C0], P = dt_conv2d_upsampled_dgrad_rows(desc),
+ * receives the BatchNorm-backward sums like dt_upsample2x_bwd_bn; fuse = NULL: plain gradient. */
+int dt_conv2d_upsampled_dgrad_supported(const dt_conv_desc* desc);
+int dt_conv2d_upsampled_dgrad_rows(const dt_conv_desc* desc);
+int dt_conv2d_upsampled_dgrad(const dt_conv_desc* desc, const float* dy, const float* w_hwio, float* gx, float* red,
+                              const dt_bn_bwd_fuse* fuse, void* stream);
 int dt_upsample2x_bwd_bn_bf16_rows(int B, int H, int W, int C);
 int dt_upsample2x_bwd_bn_bf16(const void* dup, void* dx, const dt_bn_bwd_fuse* fuse, float* red, int B, int H, int W,
                               int C, void* stream);

@@ -107,11 +107,14 @@ def test_conv_dgrad_stride2_via_zero_insert(Cin, Cout, k, p):
     assert rel_err(to_nchw(dx), x.grad) < 2e-6
 
 
-def test_conv_n16_with_virtual_upsample():
-    """dec.4.conv1: nearest x2 upsample (no skip) feeding the 16-output-channel kernel, with BN statistics"""
+@pytest.mark.parametrize("h,w_,Cin,Cout", [(20, 24, 32, 16), (21, 19, 32, 16), (64, 64, 16, 16), (9, 40, 16, 32), (4, 16, 32, 16)])
+def test_conv_n16_with_virtual_upsample(h, w_, Cin, Cout):
+    """dec.4.conv1: nearest x2 upsample (no skip) feeding the narrow-layer kernels, with BN statistics.  Round 3: the
+    sub-pixel form (conv3x3_f32_upc_kernel: 4 combined taps per output parity from the low-resolution halo) — ragged
+    maps, borders (the padding of the up-sampled image = out-of-range source pixels), every channel combination it takes"""
     ops = _ops()
-    g = torch.Generator().manual_seed(77)
-    B, h, w_, Cin, Cout = 2, 20, 24, 32, 16
+    g = torch.Generator().manual_seed(77 + h)
+    B = 2
     a = torch.randn((B, Cin, h, w_), generator=g)
     wt = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.08
     ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest").double(), wt.double(), padding=1)
@@ -120,6 +123,40 @@ def test_conv_n16_with_virtual_upsample():
     np.testing.assert_allclose(stats[0].double().sum(0).cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-5,
                                atol=1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max()))
     np.testing.assert_allclose(stats[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-5)
+
+
+@pytest.mark.parametrize("h,w_,Cin,Cout", [(20, 24, 32, 16), (21, 19, 32, 16), (64, 64, 16, 16), (9, 40, 16, 32), (4, 16, 32, 16)])
+def test_conv_upsampled_dgrad_subpixel(h, w_, Cin, Cout):
+    """dec.4.conv1 backward: autograd of conv3x3(interpolate(x, 2, nearest)) w.r.t. x in one 4x4 / stride-2 kernel
+    (conv3x3_f32_upc_dgrad_kernel, 16 combined weight matrices), with the BatchNorm-backward sums of the layer that
+    produced x in the epilogue — ragged maps and borders; against float64 autograd"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(177 + h)
+    B = 2
+    yraw = torch.randn((B, Cin, h, w_), generator=g)
+    sc = 1 + 0.3 * torch.randn(Cin, generator=g)
+    sh = 0.2 * torch.randn(Cin, generator=g)
+    mu = 0.1 * torch.randn(Cin, generator=g)
+    istd = 1 + 0.2 * torch.rand(Cin, generator=g)
+    wt = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.08
+    x = F.relu(yraw.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).requires_grad_(True)
+    out = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt.double(), padding=1)
+    dy = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dy)
+    gx, none = ops.conv2d_upsampled_dgrad(nhwc(dy), hwio(wt), Cin)
+    assert none is None
+    assert rel_err(to_nchw(gx), x.grad) < 2e-6
+    gx2, red = ops.conv2d_upsampled_dgrad(nhwc(dy), hwio(wt), Cin, y=nhwc(yraw), mean=mu.to(DEV), invstd=istd.to(DEV),
+                                          act_scale=sc.to(DEV), act_shift=sh.to(DEV))
+    assert torch.equal(gx, gx2)
+    # reference sums: over the masked gradient (mask = activation > 0, recomputed in fp32 like the kernel does)
+    mask = (yraw * sc[None, :, None, None] + sh[None, :, None, None]) > 0
+    gm = torch.where(mask, x.grad, torch.zeros_like(x.grad))
+    xhat = (yraw.double() - mu.double()[None, :, None, None]) * istd.double()[None, :, None, None]
+    s1, s2 = gm.sum(dim=(0, 2, 3)), (gm * xhat).sum(dim=(0, 2, 3))
+    tol = 2e-5 * float(gm.abs().sum(dim=(0, 2, 3)).max())
+    np.testing.assert_allclose(red[0].double().sum(0).cpu(), s1, rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(red[1].double().sum(0).cpu(), s2, rtol=1e-5, atol=tol * 3)
 
 
 @pytest.mark.parametrize("Cin,Cout,up", [(64, 64, False), (32, 16, True), (128, 32, True), (16, 16, False)])
