@@ -201,6 +201,9 @@ def kernel_family(name: str):
                 PEAK_HBM_GBS, "GB/s")
     if name.startswith("conv_fwd_bf16"):
         return ("bf16 register-staged convolution (Cout <= 32, stride 2, 1x1, stem)", "mfma", 1.0, mf, "TFLOP/s")
+    if name.startswith("conv3x3_f32_upc"):   # 16 of the 36 direct multiplies per source pixel are issued
+        return ("fp32 sub-pixel convolution of the up-sampled narrow layer (forward: 4 combined taps per output parity; "
+                "data gradient: one 4x4 stride-2 kernel)", "mfma", 16.0 / 36.0, mf, "TFLOP/s")
     if name.startswith("conv3x3_f32_narrow"):
         return ("fp32 narrow-layer convolution forward / data gradient (Cin, Cout <= 32 at full resolution)", "mfma", 1.0, mf,
                 "TFLOP/s")

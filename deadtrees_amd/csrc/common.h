@@ -70,6 +70,7 @@ int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* d
 // ---- lean persistent kernel of the narrow full-resolution decoder layers (conv_narrow.hip, round 3): Cin, Cout in {16, 32}
 extern "C" int dt_conv2d_narrow_supported(const dt_conv_desc* d);
 int dt_conv2d_narrow_rows(const dt_conv_desc* d);
+int dt_conv2d_narrow_subpixel(const dt_conv_desc* d);
 int dt_conv2d_narrow_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
                             const float* in_scale, const float* in_shift, hipStream_t st, const dt_bn_bwd_fuse* fuse,
                             bool affine = false);

@@ -757,7 +757,7 @@ extern "C" int dt_conv2d_config(const dt_conv_desc* d, int* tw, int* tn, int* ck
   if (dt_conv2d_narrow_supported(d)) {   // conv3x3_f32_narrow_kernel<CB, NB, ...>: reported as ck = 1000 + 10 CB + NB
     if (tw) *tw = 32;
     if (tn) *tn = d->Cout;
-    if (ck) *ck = 1000 + 10 * (d->C0 / 16) + d->Cout / 16;
+    if (ck) *ck = (dt_conv2d_narrow_subpixel(d) ? 2000 : 1000) + 10 * (d->C0 / 16) + d->Cout / 16;   // 2000 +: conv3x3_f32_upc_kernel
     return DT_OK;
   }
   if (dt_conv2d_n16_supported(d)) {   // conv_fwd_n16_kernel: 8x32 pixel tile, 16 output channels, CK 16

@@ -505,6 +505,14 @@ __global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narro
     __syncthreads();
     if (PREFETCH && round + 1 < my_tiles) issue_loads(round + 1);
 
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * N16_TH, ox0 = tx * N16_TW;
+    const bool interior = oy0 + N16_TH <= a.Hin && ox0 + N16_TW <= a.Win;
+    // output addresses: one base per lane and tile + the row stride; the rest are immediates
+    const size_t o00 = (((size_t)b * a.Hin + oy0 + 2 * wave) * a.Win + ox0 + 4 * kq) * COUT + m;
+    const size_t orow = (size_t)a.Win * COUT;
+
     f32x4 acc[4][NB];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
@@ -541,10 +549,6 @@ __global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narro
     }
 
     // ---- epilogue: D col = channel 16 nb + m, row = pixel column 4 kq + i of the M block
-    const int sp = tile_of(round);
-    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
-    const int oy0 = ty * N16_TH, ox0 = tx * N16_TW;
-    const bool interior = oy0 + N16_TH <= a.Hin && ox0 + N16_TW <= a.Win;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int oy = oy0 + 2 * wave + (mb >> 1);
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narro
       for (int i = 0; i < 4; ++i) {
         const int ox = ox0 + 16 * (mb & 1) + 4 * kq + i;
         if (interior || (oy < a.Hin && ox < a.Win)) {
-          const size_t o = (((size_t)b * a.Hin + oy) * a.Win + ox) * COUT + m;
+          const size_t o = o00 + (mb >> 1) * orow + (16 * (mb & 1) + i) * COUT;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             float v = acc[mb][nb][i];
@@ -561,6 +565,7 @@ __global__ __launch_bounds__(256, (CB * NB == 1) ? 3 : 2) void conv3x3_f32_narro
               v = v < 0.f ? 0.f : v;
             }
             if constexpr (EPI == 1) {
+              // (requesting y ahead of the MFMA loop — 16 NB registers — changed nothing: 792 / 787 vs 788 / 786 tiles/s)
               const float yv = a.bnb.y[o + 16 * nb];
               const float g = (yv * b_sc[nb] + b_sh[nb]) > 0.f ? v : 0.f;
               s1[nb] += g;
@@ -661,6 +666,11 @@ static int nl_launch(const NarrowLeanArgs& a, int total, bool tf, int epi, hipSt
 
 int dt_conv2d_narrow_launch_upc(const dt_conv_desc* d, const NarrowLeanArgs& a, int total, bool tf, int epi, hipStream_t st);
 
+static bool nl_upc_enabled();
+// 1 when the (supported) narrow layer runs in its sub-pixel form
+int dt_conv2d_narrow_subpixel(const dt_conv_desc* d) {
+  return d->mode0 == 1 && nl_upc_enabled() && ((d->Hin | d->Win) & 1) == 0 && d->C0 * d->Cout <= 512;
+}
 static bool nl_upc_enabled() {
   static const int on = [] {
     const char* e = getenv("DT_FP32_SUBPIXEL");
@@ -687,7 +697,7 @@ int dt_conv2d_narrow_launch(const dt_conv_desc* d, const float* src0, const floa
   a.P = dt_conv2d_narrow_rows(d);
   const int total = nl_tiles(d), epi = affine ? 4 : (bnb ? 1 : 0);
   int rc;
-  if (d->mode0 == 1 && epi != 1 && nl_upc_enabled() && ((d->Hin | d->Win) & 1) == 0 && d->C0 * d->Cout <= 512) {
+  if (epi != 1 && dt_conv2d_narrow_subpixel(d)) {
     // nearest-upsampled input: the sub-pixel form (4 combined taps per output parity instead of 9); 32 -> 32 would
     // need 256 weight registers and keeps the 9-tap form
     rc = dt_conv2d_narrow_launch_upc(d, a, total, tf, epi, st);
@@ -1065,6 +1075,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_upc_dgrad_kernel(const Upc
     __syncthreads();
     if (round + 1 < my_tiles) issue_loads(round + 1);
 
+    const int sp = tile_of(round);
+    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
+    const int Y = 4 * ty + wave;
     f32x4 acc[CIB];
 #pragma unroll
     for (int nb = 0; nb < CIB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1088,9 +1101,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_upc_dgrad_kernel(const Upc
     }
 
     // ---- epilogue: low-resolution pixel (4 ty + w, 16 tx + 4 kq + i), channel 16 nb + m
-    const int sp = tile_of(round);
-    const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / (a.tiles_x * a.tiles_y);
-    const int Y = 4 * ty + wave;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int X = 16 * tx + 4 * kq + i;
@@ -1138,7 +1148,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_upc_dgrad_kernel(const Upc
 // `d` describes the FORWARD convolution (mode0 = 1, C0 = CI low-resolution input channels, Cout = CO, Hin x Win = the
 // full-resolution map)
 extern "C" int dt_conv2d_upsampled_dgrad_supported(const dt_conv_desc* d) {
-  if (!nl_enabled() || !nl_upc_enabled() || d == nullptr) return 0;
+  static const int on = [] {
+    const char* e = getenv("DT_FP32_SUBPIXEL_DGRAD");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  if (!on || !nl_enabled() || !nl_upc_enabled() || d == nullptr) return 0;
   if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->mode0 != 1 || d->C1 != 0 || d->cout_split != 0) return 0;
   if ((d->C0 != 16 && d->C0 != 32) || (d->Cout != 16 && d->Cout != 32) || d->C0 * d->Cout > 512) return 0;
   if (((d->Hin | d->Win) & 1) != 0 || d->Ho != d->Hin || d->Wo != d->Win || d->Win < 32 || d->Hin < 8) return 0;

@@ -145,6 +145,9 @@ class UNetEngine:
         """name of the kernel instantiation dt_conv2d launches, spelled like rocprofv3 prints it"""
         tw, tn, ck = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self.lib.dt_conv2d_config(C.byref(desc), C.byref(tw), C.byref(tn), C.byref(ck)), "dt_conv2d_config")
+        if ck.value >= 2000:     # its sub-pixel form for the up-sampled input: ck = 2000 + 10 CB + NB
+            cb, nbk = (ck.value - 2000) // 10, (ck.value - 2000) % 10
+            return f"conv3x3_f32_upc_kernel<{cb}, {nbk}, {'true' if transformed else 'false'}>"
         if ck.value >= 1000:     # the lean narrow-layer kernel (conv_narrow.hip): ck = 1000 + 10 CB + NB
             cb, nbk = (ck.value - 1000) // 10, (ck.value - 1000) % 10
             return f"conv3x3_f32_narrow_kernel<{cb}, {nbk}, {'true' if transformed else 'false'}, false>"
