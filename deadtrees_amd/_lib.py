@@ -56,6 +56,7 @@ SIGNATURES = {
     "dt_winograd_weight_images": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_conv2d_winograd_affine": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_narrow_supported": (C.c_int, [_P]),
+    "dt_conv2d_affine": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, c_f]),
     "dt_conv2d_narrow_affine": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "dt_conv2d_winograd_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),

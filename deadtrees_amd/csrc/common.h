@@ -71,6 +71,8 @@ int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* d
 extern "C" int dt_conv2d_narrow_supported(const dt_conv_desc* d);
 int dt_conv2d_narrow_rows(const dt_conv_desc* d);
 int dt_conv2d_narrow_subpixel(const dt_conv_desc* d);
+extern "C" int dt_conv2d_narrow_affine(const dt_conv_desc* d, const float* src0, const float* w_hwio, float* out, const float* scale,
+                                       const float* shift, const float* in_scale, const float* in_shift, void* stream);
 int dt_conv2d_narrow_launch(const dt_conv_desc* d, const float* src0, const float* w, float* out, float* stats,
                             const float* in_scale, const float* in_shift, hipStream_t st, const dt_bn_bwd_fuse* fuse,
                             bool affine = false);

@@ -28,11 +28,17 @@ struct ConvArgs {
   __bf16* out0_bf16;      // when set (bf16 training path, stem): out0 is written as bf16 instead (no split/accumulate)
   float* out1;
   float* stats;
+  const float* aff_scale;  // inference epilogue (dt_conv2d_affine): out = [relu](conv * scale + shift), eval-mode BatchNorm
+  const float* aff_shift;  // on the accumulators (bn_act's mul, add, NaN-keeping ReLU); no statistics
+  int aff_relu;
   // fused BatchNorm-backward reduction (dt_conv2d_bn_bwd): when bnb.y is set, `stats` receives sum g, sum g*xhat
   dt_bn_bwd_fuse bnb;
   int B, Hin, Win, C0, C1, mode0;
   int Ho, Wo, Cout, cout_split, pad, accumulate;
   int tiles_x, tiles_y, n_tiles, P;
+  int sp_tiles;
+  int pack;   // 1: a tile = four images of <= 8 x 8 output pixels (layer4.0.conv1 of a 256-pixel tile): rows 8 k .. 8 k + 7 of
+              // the 8 x 32 tile belong to image 4 sp + k — without it three quarters of every M tile were padding
 };
 
 __host__ __device__ constexpr int plane_pad(int n, int mod8) {
@@ -47,7 +53,10 @@ struct ConvGeom {
   static constexpr int TH = 256 / TW;
   static constexpr int LS = (KS == 1) ? 1 : STRIDE;  // pixel step inside the LDS tile
   static constexpr int GS = (KS == 1) ? STRIDE : 1;  // pixel step in global memory per LDS pixel
-  static constexpr int HALO_H = (TH - 1) * LS + KS;
+  // 8-wide stride-2 3x3 tiles (32 rows) can hold four images of at most 8 x 8 output pixels (ConvArgs::pack): each
+  // image's 17 halo rows (input rows -1 .. 15) are kept apart, 4 x 17 = 68 rows instead of 65
+  static constexpr bool PACKABLE = KS == 3 && STRIDE == 2 && TW == 8;
+  static constexpr int HALO_H = PACKABLE ? 68 : (TH - 1) * LS + KS;
   static constexpr int HALO_W = (TW - 1) * LS + KS;
   static constexpr int PMOD = (CK >= 32) ? 1 : (CK == 16 ? 2 : (CK == 8 ? 4 : 0));
   static constexpr int PLANE = plane_pad(HALO_H * HALO_W, PMOD);
@@ -282,6 +291,7 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
     int py, px, cy, cx;
     tile_pixel<ZI, TW>(wave, mt, r, py, px, cy, cx);
     abase[mt] = s * G::PLANE + py * G::LS * G::HALO_W + px * G::LS;
+    if (G::PACKABLE && a.pack) abase[mt] += (py >> 3) * G::HALO_W;   // image k's halo starts at row 17 k, not 16 k
   }
   const int bbase = s * TN + r;
 
@@ -353,13 +363,19 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
     for (int it = 0; it < IN_IT; ++it) {
       const int pix = pix0 + it * (256 / QI);
       const int hy = pix / G::HALO_W, hx = pix - hy * G::HALO_W;
-      const int iy = iy0 + hy * G::GS, ix = ix0 + hx * G::GS;
-      const bool inb = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && pix < G::HALO_H * G::HALO_W;
+      int iy = iy0 + hy * G::GS, bb = b;
+      const int ix = ix0 + hx * G::GS;
+      if (G::PACKABLE && a.pack) {          // halo rows 17 k .. 17 k + 16 = input rows -1 .. 15 of image 4 sp + k
+        bb = 4 * sp + hy / 17;
+        iy = hy % 17 - a.pad;
+      }
+      const bool inb = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && pix < G::HALO_H * G::HALO_W &&
+                       bb < a.B;
       bool ok0 = inb;
       if (a.mode0 == 2) ok0 = ok0 && (((iy | ix) & 1) == 0);
       const int sy = a.mode0 ? (iy >> 1) : iy, sx = a.mode0 ? (ix >> 1) : ix;
-      pidx0[it] = ok0 ? (b * Hs0 + sy) * Ws0 + sx : -1;
-      pidx1[it] = inb ? (b * a.Hin + iy) * a.Win + ix : -1;
+      pidx0[it] = ok0 ? (bb * Hs0 + sy) * Ws0 + sx : -1;
+      pidx1[it] = inb ? (bb * a.Hin + iy) * a.Win + ix : -1;
     }
     int woff[W_IT];
 #pragma unroll
@@ -473,9 +489,14 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
         const int mrow = (i & 3) + 8 * (i >> 2) + 4 * s;
         int ty_, tx_, cy, cx;
         tile_pixel<ZI, TW>(wave, mt, mrow, ty_, tx_, cy, cx);
-        const int oy = oy0 + ty_, ox = ox0 + tx_;
-        ok[i] = nok && oy < a.Ho && ox < a.Wo;
-        off[i] = (((size_t)b * a.Ho + oy) * a.Wo + ox) * ld + nn;
+        int oy = oy0 + ty_, bb = b;
+        const int ox = ox0 + tx_;
+        if (G::PACKABLE && a.pack) {
+          bb = 4 * sp + (ty_ >> 3);
+          oy = ty_ & 7;
+        }
+        ok[i] = nok && oy < a.Ho && ox < a.Wo && bb < a.B;
+        off[i] = (((size_t)bb * a.Ho + oy) * a.Wo + ox) * ld + nn;
       }
       if (a.accumulate && outp == a.out0) {
         float prev[16];   // all 16 loads in flight before the first add (gradient accumulation joins)
@@ -518,6 +539,15 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
             s2[j] += g * ((yv[i] - b_mu) * b_is);
             outp[off[i]] = v;
           }
+      } else if (a.aff_scale != nullptr) {
+        const float e_sc = nok ? a.aff_scale[n] : 0.f, e_sh = nok ? a.aff_shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (ok[i]) {
+            float v = acc[mt][j][i] * e_sc + e_sh;
+            if (a.aff_relu) v = v < 0.f ? 0.f : v;
+            outp[off[i]] = v;
+          }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
@@ -547,7 +577,14 @@ __global__ __launch_bounds__(256, (KS == 3 && STRIDE == 1 && CK == 8 && TN == 32
     }
     __syncthreads();
     const int t = threadIdx.x;
-    if (t < 2 * TN) {
+    if (G::PACKABLE && a.pack) {
+      // wave w holds image 4 sp + w (in the pixel order of a tile of its own): one row per IMAGE, the same partial sums
+      // as without packing
+      for (int idx = t; idx < 8 * TN; idx += 256) {
+        const int which = idx / (4 * TN), wv = (idx / TN) & 3, c = idx % TN, img = 4 * sp + wv;
+        if (img < a.B && n0 + c < a.Cout) a.stats[((size_t)which * a.P + img) * a.Cout + n0 + c] = red[which * 4 * TN + wv * TN + c];
+      }
+    } else if (t < 2 * TN) {
       const int which = t / TN, c = t % TN;
       if (n0 + c < a.Cout) {
         const float* rr = red + which * 4 * TN + c;
@@ -563,6 +600,12 @@ struct ConvCfg {
   int tw, tn;
 };
 
+// stride-2 3x3 layers with maps of at most 8 x 8 output pixels: four images share an 8 x 32 tile (ConvArgs::pack)
+static int conv_packs(const dt_conv_desc* d) {
+  return d->ksize == 3 && d->stride == 2 && d->pad == 1 && d->mode0 == 0 && d->C1 == 0 && d->Ho <= 8 && d->Wo <= 8 &&
+         d->Hin <= 16 && d->B >= 2;
+}
+
 static ConvCfg pick_cfg(const dt_conv_desc* d) {
   ConvCfg c;
   c.tw = d->Wo > 16 ? 32 : (d->Wo > 8 ? 16 : 8);
@@ -571,7 +614,8 @@ static ConvCfg pick_cfg(const dt_conv_desc* d) {
   // keep >= 2 workgroups per CU in flight when the grid is small (deep layers: few spatial tiles)
   if (tn == 64) {
     const int th = 256 / c.tw;
-    const long wgs = (long)d->B * dt_cdiv(d->Ho, th) * dt_cdiv(d->Wo, c.tw) * dt_cdiv(d->Cout, 64);
+    const long sp = conv_packs(d) ? dt_cdiv(d->B, 4) : (long)d->B * dt_cdiv(d->Ho, th) * dt_cdiv(d->Wo, c.tw);
+    const long wgs = sp * dt_cdiv(d->Cout, 64);
     if (wgs < 512) tn = 32;
   }
   c.tn = tn;
@@ -604,7 +648,7 @@ extern "C" int dt_conv2d_stat_rows(const dt_conv_desc* d) {
 
 template <int KS, int STRIDE, int TW, int TN, int CK, bool ZI = false>
 static int launch(const ConvArgs& a, hipStream_t st) {
-  const long grid = (long)a.P * a.n_tiles;
+  const long grid = (long)a.sp_tiles * a.n_tiles;
   if constexpr (KS == 3 && STRIDE == 1 && !ZI) {
     if (a.in_scale != nullptr) {
       hipLaunchKernelGGL((conv_fwd_kernel<KS, STRIDE, TW, TN, CK, false, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
@@ -636,7 +680,19 @@ static int launch_tw_tn(const ConvArgs& a, const ConvCfg& c, hipStream_t st) {
 
 static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* w, float* out0,
                        float* out1, float* stats, const float* in_scale, const float* in_shift, void* out_bf16,
-                       void* stream, const dt_bn_bwd_fuse* fuse = nullptr);
+                       void* stream, const dt_bn_bwd_fuse* fuse = nullptr, const float* aff_scale = nullptr,
+                       const float* aff_shift = nullptr, int aff_relu = 0);
+
+// inference: out = [relu](conv(x) * scale + shift) in one launch — eval-mode BatchNorm (+ ReLU) of the layers that are
+// neither Winograd layers (dt_conv2d_winograd_affine) nor narrow ones (dt_conv2d_narrow_affine): the stem, the stride-2
+// 3x3 and the 1x1 down-sample convolutions, dec3.conv1 (reference: model.eval() forward of
+// segmentation_models_pytorch Unet via deadtrees/network/segmodel.py:151-153 -> Conv2d + BatchNorm2d [+ ReLU])
+extern "C" int dt_conv2d_affine(const dt_conv_desc* d, const float* src0, const float* src1, const float* w, float* out,
+                                const float* scale, const float* shift, int relu, void* stream) {
+  DT_REQUIRE(d && scale && shift, "conv_affine: null pointer");
+  DT_REQUIRE(d->cout_split == 0 && d->accumulate == 0, "conv_affine: no split / join");
+  return conv2d_impl(d, src0, src1, w, out, nullptr, nullptr, nullptr, nullptr, nullptr, stream, nullptr, scale, shift, relu);
+}
 
 extern "C" int dt_conv2d(const dt_conv_desc* d, const float* src0, const float* src1, const float* w,
                          float* out0, float* out1, float* stats, const float* in_scale, const float* in_shift,
@@ -659,7 +715,8 @@ extern "C" int dt_conv2d_bn_bwd(const dt_conv_desc* d, const float* src0, const 
 
 static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* src1, const float* w, float* out0,
                        float* out1, float* stats, const float* in_scale, const float* in_shift, void* out_bf16,
-                       void* stream, const dt_bn_bwd_fuse* fuse) {
+                       void* stream, const dt_bn_bwd_fuse* fuse, const float* aff_scale, const float* aff_shift,
+                       int aff_relu) {
   int rc = validate(d);
   if (rc != DT_OK) return rc;
   DT_REQUIRE(src0 && w && out0, "conv: null pointer");
@@ -668,22 +725,27 @@ static int conv2d_impl(const dt_conv_desc* d, const float* src0, const float* sr
   DT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv: in_scale/in_shift must come together");
   DT_REQUIRE(in_scale == nullptr || (d->ksize == 3 && d->stride == 1 && d->mode0 != 2 && d->C0 <= DT_TF_MAXC),
              "conv: input transform needs a 3x3 stride-1 layer with C0 <= %d and no zero-insertion", DT_TF_MAXC);
-  if (out_bf16 == nullptr && dt_conv2d_narrow_supported(d))   // Cin, Cout in {16, 32} at full resolution: the lean kernel
+  if (aff_scale != nullptr && aff_relu && src1 == nullptr && dt_conv2d_narrow_supported(d))
+    return dt_conv2d_narrow_affine(d, src0, w, out0, aff_scale, aff_shift, nullptr, nullptr, stream);
+  if (aff_scale == nullptr && out_bf16 == nullptr && dt_conv2d_narrow_supported(d))   // Cin, Cout in {16, 32} at full resolution: the lean kernel
     return dt_conv2d_narrow_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream, fuse);
-  if (dt_conv2d_n16_supported(d))
+  if (aff_scale == nullptr && dt_conv2d_n16_supported(d))
     return dt_conv2d_n16_launch(d, src0, w, out0, stats, in_scale, in_shift, (hipStream_t)stream, fuse);
   ConvCfg c = pick_cfg(d);
   ConvArgs a;
   a.bnb = fuse ? *fuse : dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   a.src0 = src0; a.src1 = src1; a.w = w; a.out0 = out0; a.out1 = out1; a.stats = stats;
   a.in_scale = in_scale; a.in_shift = in_shift; a.out0_bf16 = (__bf16*)out_bf16;
+  a.aff_scale = aff_scale; a.aff_shift = aff_shift; a.aff_relu = aff_relu;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0;
   a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.cout_split = d->cout_split; a.pad = d->pad;
   a.accumulate = d->accumulate;
   a.tiles_x = dt_cdiv(d->Wo, c.tw);
   a.tiles_y = dt_cdiv(d->Ho, 256 / c.tw);
   a.n_tiles = dt_cdiv(d->Cout, c.tn);
-  a.P = d->B * a.tiles_x * a.tiles_y;
+  a.pack = conv_packs(d);
+  a.P = d->B * a.tiles_x * a.tiles_y;            // statistics rows (packed tiles: still one per image)
+  a.sp_tiles = a.pack ? dt_cdiv(d->B, 4) : a.P;  // spatial tiles of the grid
   hipStream_t st = (hipStream_t)stream;
   if (d->mode0 == 2 && d->stride == 1 && c.tw == 32 && d->C0 > 32) {   // transposed conv: parity-class tiles
     if (d->ksize == 3) return c.tn == 64 ? launch<3, 1, 32, 64, 16, true>(a, st) : launch<3, 1, 32, 32, 16, true>(a, st);

@@ -311,6 +311,29 @@ class UNetEngine:
         self._pe(e0, "bn_act_kernel", 0.0, 4.0 * y.numel() * (2 + (res is not None)))
         return z
 
+    def _conv_affine_direct(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, relu=True):
+        """inference: [relu](bn_eval(conv(x))) in one launch of the direct kernel (dt_conv2d_affine) — the layers that are
+        neither Winograd nor narrow layers: stem, stride-2 3x3, 1x1 down-sample.  Returns (activation, Ho, Wo)."""
+        Ho = (Hin + 2 * c.pad - c.k) // c.stride + 1
+        Wo = (Win + 2 * c.pad - c.k) // c.stride + 1
+        C0 = src0.shape[-1]
+        C1 = 0 if src1 is None else src1.shape[-1]
+        desc = self._desc(B, Hin, Win, C0, C1, mode0, Ho, Wo, c.cout, c.k, c.stride, c.pad)
+        scale, shift = self._ss(c, bnws)
+        if not self._affine_fresh:
+            _lib.check(self.lib.dt_bn_eval_affine(_p(params[c.g_off:c.g_off + c.cout]), _p(params[c.b_off:c.b_off + c.cout]),
+                                                  _p(bnstate[2 * c.bn_off: 2 * c.bn_off + c.cout]),
+                                                  _p(bnstate[2 * c.bn_off + c.cout: 2 * c.bn_off + 2 * c.cout]), BN_EPS,
+                                                  c.cout, _p(scale), _p(shift), _stream()), "dt_bn_eval_affine")
+        z = torch.empty((B, Ho, Wo, c.cout), dtype=torch.float32, device=src0.device)
+        e0 = self._pb()
+        _lib.check(self.lib.dt_conv2d_affine(C.byref(desc), _p(src0), _p(src1), _p(params[c.w_off:c.w_off + c.w_size]), _p(z),
+                                             _p(scale), _p(shift), 1 if relu else 0, _stream()), "dt_conv2d_affine")
+        if e0 is not None:
+            fl, nb = self._conv_work(desc)
+            self._pe(e0, self._conv_kernel_name(desc, False), fl, nb)
+        return z, Ho, Wo
+
     def _conv_affine_eval(self, c: ConvSpec, params, bnstate, bnws, src0, src1, mode0, B, Hin, Win, res=None, in_ss=None):
         """inference: relu(bn_eval(conv(x)) [+ res]) in ONE Winograd launch (dt_conv2d_winograd_affine) — no raw output, no
         bn_act pass.  Returns the activation, or None when the layer is not a Winograd layer (caller: conv + bn_act)."""
@@ -405,9 +428,12 @@ class UNetEngine:
                 sv.d[key] = kw
 
         # ---- stem
-        y, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, training, save_stats=save)
-        f1 = self._bn_act(y, ss)
-        keep("stem", x=x, y=y, z=f1, Hin=H, Win=W)
+        if self._fuse_eval:     # inference: BatchNorm + ReLU in the stem kernel's epilogue, no raw output
+            f1, h, w_ = self._conv_affine_direct(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W)
+        else:
+            y, h, w_, ss = self._conv_bn(sp.stem, params, bnstate, bnws, x, None, 0, B, H, W, training, save_stats=save)
+            f1 = self._bn_act(y, ss)
+            keep("stem", x=x, y=y, z=f1, Hin=H, Win=W)
         hp, wp = (h + 2 - 3) // 2 + 1, (w_ + 2 - 3) // 2 + 1
         pool = torch.empty((B, hp, wp, 64), dtype=torch.float32, device=dev)
         amax = torch.empty((B, hp, wp, 64), dtype=torch.uint8, device=dev) if save else None
@@ -425,6 +451,15 @@ class UNetEngine:
                                                                          ch, cw, res=xin)
                     if out is not None:
                         cur = out
+                        continue
+                if self._fuse_eval and blk.down is not None and blk.conv2.cout % 64 == 0:
+                    # first block of layers 2-4: relu(bn1(conv1)) and bn_d(down(x)) from the direct kernel's epilogue, the
+                    # join relu(bn2(conv2) + .) in the Winograd kernel's
+                    z1, h1, w1 = self._conv_affine_direct(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw)
+                    rd, _, _ = self._conv_affine_direct(blk.down, params, bnstate, bnws, xin, None, 0, B, ch, cw, relu=False)
+                    out = self._conv_affine_eval(blk.conv2, params, bnstate, bnws, z1, None, 0, B, h1, w1, res=rd)
+                    if out is not None:
+                        cur, ch, cw = out, h1, w1
                         continue
                 y1, h1, w1, ss1 = self._conv_bn(blk.conv1, params, bnstate, bnws, xin, None, 0, B, ch, cw, training,
                                                         save_stats=save)

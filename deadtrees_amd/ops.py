@@ -66,6 +66,21 @@ def conv2d(src0, w_hwio, k, stride, pad, src1=None, mode0=0, split=0, out0=None,
     return out0, out1, stats
 
 
+def conv2d_affine(src0, w_hwio, k, stride, pad, scale, shift, relu=True, src1=None, mode0=0):
+    """inference form through dt_conv2d_affine: [relu](conv(x) * scale + shift) in one launch (eval-mode BatchNorm folded
+    into per-channel scale / shift) -> NHWC activation"""
+    _gpu(src0, src1, w_hwio, scale, shift)
+    B, C0 = src0.shape[0], src0.shape[-1]
+    C1 = 0 if src1 is None else src1.shape[-1]
+    Hin, Win = (src0.shape[1], src0.shape[2]) if mode0 == 0 else (2 * src0.shape[1], 2 * src0.shape[2])
+    Cout = w_hwio.shape[-1]
+    d = conv_desc(B, Hin, Win, C0, C1, mode0, Cout, k, stride, pad)
+    out = torch.empty((B, d.Ho, d.Wo, Cout), dtype=torch.float32, device=src0.device)
+    _lib.check(_lib.load().dt_conv2d_affine(C.byref(d), _p(src0), _p(src1), _p(w_hwio.contiguous()), _p(out), _p(scale),
+                                            _p(shift), 1 if relu else 0, _st()), "dt_conv2d_affine")
+    return out
+
+
 def conv2d_wgrad_winograd(src0, dy, src1=None, mode0=0, in_scale=None, in_shift=None):
     """3x3 stride-1 pad-1 weight gradient through dt_conv2d_wgrad_winograd -> dw HWIO"""
     _gpu(src0, src1, dy)

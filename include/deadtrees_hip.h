@@ -98,6 +98,11 @@ int dt_conv2d_winograd_affine(const dt_conv_desc* d, const float* src0, const fl
 int dt_conv2d_narrow_supported(const dt_conv_desc* d);
 int dt_conv2d_narrow_affine(const dt_conv_desc* d, const float* src0, const float* w_hwio, float* out, const float* scale,
                             const float* shift, const float* in_scale, const float* in_shift, void* stream);
+/* ... and for every other layer dt_conv2d takes (stem 7x7 / 2, stride-2 3x3, 1x1 down-sample, concat layers): out =
+ * conv(x) * scale + shift, through ReLU when relu != 0 — bit-identical to dt_conv2d followed by dt_bn_act(relu).  No
+ * input transform, split, join or statistics. */
+int dt_conv2d_affine(const dt_conv_desc* d, const float* src0, const float* src1, const float* w_hwio, float* out,
+                     const float* scale, const float* shift, int relu, void* stream);
 /* all eligible layers in one launch: int32 table rows (w_off, u_off, Cin, Cout, first_block), blocks of a layer =
  * ceil(Cout/64) * ceil(Cin/16); `weights` = the flat parameter buffer (forward images) or its dt_weight_images mode-0
  * image with Cin/Cout swapped (data-gradient images). */

@@ -125,6 +125,63 @@ def test_conv_n16_with_virtual_upsample(h, w_, Cin, Cout):
     np.testing.assert_allclose(stats[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,h,w_,Cin,Cout", [(5, 16, 16, 64, 128), (8, 16, 16, 256, 512), (2, 13, 11, 32, 64), (3, 16, 9, 16, 32)])
+def test_conv_stride2_small_maps_share_a_tile(B, h, w_, Cin, Cout):
+    """layer4.0.conv1 of a 256-pixel tile (16x16 -> 8x8): four images share one 8 x 32-pixel tile of the stride-2 kernel
+    (ConvArgs::pack) — image borders stay zero padding (no bleed between neighbours in the tile), ragged groups (B % 4),
+    maps smaller than 8 x 8, BatchNorm statistics over all images"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 31 + h)
+    a = torch.randn((B, Cin, h, w_), generator=g)
+    wt = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.05
+    ref = F.conv2d(a.double(), wt.double(), stride=2, padding=1)
+    y, _, stats = ops.conv2d(nhwc(a), hwio(wt), 3, 2, 1, want_stats=True)
+    assert tuple(y.shape) == (B, ref.shape[2], ref.shape[3], Cout)
+    assert rel_err(to_nchw(y), ref) < 2e-6
+    np.testing.assert_allclose(stats[0].double().sum(0).cpu(), ref.sum(dim=(0, 2, 3)), rtol=1e-5,
+                               atol=1e-4 * float(ref.abs().sum(dim=(0, 2, 3)).max()))
+    np.testing.assert_allclose(stats[1].double().sum(0).cpu(), (ref * ref).sum(dim=(0, 2, 3)), rtol=1e-5)
+    # one image alone (no packing: B = 1) gives the same bits as the same image inside a group
+    y1, _, _ = ops.conv2d(nhwc(a[B - 1:]), hwio(wt), 3, 2, 1)
+    assert torch.equal(y1[0], y[B - 1])
+
+
+@pytest.mark.parametrize("k,s,p,Cin,Cout,h,w_,relu,C1,up", [
+    (7, 2, 3, 3, 64, 64, 96, True, 0, False),      # stem
+    (7, 2, 3, 4, 64, 37, 41, True, 0, False),      # RGBN stem, ragged
+    (3, 2, 1, 64, 128, 32, 48, True, 0, False),    # layerN.0.conv1
+    (3, 2, 1, 256, 512, 16, 16, True, 0, False),   # layer4.0.conv1 at a 256-pixel tile
+    (1, 2, 0, 64, 128, 32, 48, False, 0, False),   # down-sample branch: BatchNorm without ReLU
+    (3, 1, 1, 64, 32, 16, 24, True, 64, True),     # dec3.conv1: up-sampled + skip
+    (3, 1, 1, 16, 16, 16, 32, True, 0, False),     # a narrow layer (routed to the lean kernel)
+    (3, 1, 1, 16, 16, 16, 32, False, 0, False),    # ... without ReLU: the generic kernel
+])
+def test_conv_affine_epilogue_equals_conv_then_bn_act(k, s, p, Cin, Cout, h, w_, relu, C1, up):
+    """inference: dt_conv2d_affine (eval BatchNorm [+ ReLU] on the accumulators) is bit-identical to dt_conv2d followed by
+    dt_bn_act, for every kind of layer the direct kernel takes — and keeps NaN like F.relu does"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(k * 100 + Cin)
+    B = 2
+    a = torch.randn((B, h, w_, Cin), generator=g).to(DEV)
+    hs, ws = (2 * h, 2 * w_) if up else (h, w_)
+    a1 = torch.randn((B, hs, ws, C1), generator=g).to(DEV) if C1 else None
+    wt = (torch.randn((k, k, Cin + C1, Cout), generator=g) * 0.05).to(DEV)
+    sc = (1 + 0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    sh = (0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    y, _, _ = ops.conv2d(a, wt, k, s, p, src1=a1, mode0=1 if up else 0)
+    ref = ops.bn_act(y, sc, sh, relu=relu)
+    z = ops.conv2d_affine(a, wt, k, s, p, sc, sh, relu=relu, src1=a1, mode0=1 if up else 0)
+    if Cin == 16 and not relu:   # dt_conv2d runs the lean kernel here, the epilogue without ReLU the generic one: another
+        assert rel_err(z, ref) < 2e-6   # (exact-fma) summation order
+    else:
+        assert torch.equal(z, ref)
+    if relu:
+        assert float(z.min()) >= 0.0
+    a[0, h // 2, w_ // 2, 0] = float("nan")
+    z = ops.conv2d_affine(a, wt, k, s, p, sc, sh, relu=relu, src1=a1, mode0=1 if up else 0)
+    assert bool(torch.isnan(z).any())
+
+
 @pytest.mark.parametrize("h,w_,Cin,Cout", [(20, 24, 32, 16), (21, 19, 32, 16), (64, 64, 16, 16), (9, 40, 16, 32), (4, 16, 32, 16)])
 def test_conv_upsampled_dgrad_subpixel(h, w_, Cin, Cout):
     """dec.4.conv1 backward: autograd of conv3x3(interpolate(x, 2, nearest)) w.r.t. x in one 4x4 / stride-2 kernel
