@@ -567,6 +567,8 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
         from deadtrees_amd.deployment.tiler import infer_tile
 
         class _U8:
+            in_channels = 3
+
             def run_u8(self, tiles_u8, device=None):
                 x = ops.normalize_u8(tiles_u8.to(dev, non_blocking=True), MEAN, STD, 3)
                 return model.predict_classes(x, dtype="uint8", precision=args.precision, nhwc=True)

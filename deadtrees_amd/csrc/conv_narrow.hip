@@ -345,8 +345,168 @@ extern "C" int dt_conv2d_wgrad_n16_supported(const dt_conv_desc* d) {
          (d->Cout & 3) == 0 && d->Cout <= 32 && !(Cin > 16 && d->Cout > 16) && d->mode0 != 2 && d->Wo > 16;
 }
 
+// ---- sub-pixel weight gradient of the up-sampled layer (dec4.conv1): the transpose of conv3x3_f32_upc_kernel in the
+// weights.  With y[2Y+a][2X+b] = sum_{dy,dx} W'_ab[dy][dx] x[Y+a-1+dy][X+b-1+dx] (W' = sums of the 3x3 taps, see there):
+//     dW'_ab[dy][dx] = sum_{Y,X} x[Y+a-1+dy][X+b-1+dx] (x) dY[2Y+a][2X+b]      16 products per source pixel (36 direct)
+//     dW[kh][kw]     = sum over the (a,dy) with kh in R(a,dy) and the (b,dx) with kw in R(b,dx) of dW'_ab[dy][dx]
+// The 16 accumulators of a lane hold the same (ci, co) element, so the fold to nine taps is lane-local and the partial
+// slabs leave in the [part][9][Cin][Cout] layout of conv_wgrad_n16_kernel (same split-K reduction, fixed order).
+// K step = 4 source pixels of a row: nine shifted x fragments (A, M = ci) and four parity fragments of dY (B, N = co)
+// feed 16 CIT MFMAs; dY is kept parity-split in LDS ([row][column parity][32 columns]) and the pixel pitches (16 / 48
+// floats) make every ds_read_b32 of a fragment conflict-free.  Persistent over the workgroup's tiles with the next
+// tile's loads in flight.  Measured: DESIGN.md 10.
+#define UW_TW 32            // source (low-resolution) columns per tile
+#define UW_TH 4             // source rows per tile: one per wave
+#define UW_HW (UW_TW + 2)
+#define UW_HH (UW_TH + 2)
+
+template <int CIT>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_f32_upc_kernel(const NarrowWgArgs a) {
+  constexpr int CIW = 16 * CIT, COW = 16;
+  constexpr int XP = CIT == 1 ? 16 : 48;        // floats per source pixel in LDS (bank rule: kq * XP + [0, 16) disjoint mod 64)
+  constexpr int X_ELEMS = UW_HH * UW_HW * XP, Y_ELEMS = 2 * UW_TH * 2 * UW_TW * COW;
+  __shared__ __attribute__((aligned(16))) float lds[X_ELEMS + Y_ELEMS];
+  float* lx = lds;
+  float* ly = lds + X_ELEMS;
+  const int ks = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  const int Hs = a.Hin >> 1, Ws = a.Win >> 1;
+  f32x4 acc[2][2][2][2][CIT];                   // [a][b][dy][dx][ci block]
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+#pragma unroll
+    for (int i = 0; i < CIT; ++i) acc[e >> 3][(e >> 2) & 1][(e >> 1) & 1][e & 1][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int QX = CIW / 4, QY = COW / 4;
+  constexpr int X_TOTAL = UW_HH * UW_HW * QX, X_IT = (X_TOTAL + 255) / 256;
+  constexpr int Y_TOTAL = 2 * UW_TH * 2 * UW_TW * QY, Y_IT = Y_TOTAL / 256;
+  static_assert(Y_TOTAL % 256 == 0, "dY fill");
+  const int qx = tid % QX, px0 = tid / QX, qy = tid % QY, py0 = tid / QY;
+  f32x4 x_sc = {1.f, 1.f, 1.f, 1.f}, x_sh = {0.f, 0.f, 0.f, 0.f};
+  const bool tf = a.in_scale != nullptr;
+  if (tf) {
+    x_sc = *reinterpret_cast<const f32x4*>(a.in_scale + 4 * qx);
+    x_sh = *reinterpret_cast<const f32x4*>(a.in_shift + 4 * qx);
+  }
+  // fragment bases: x halo pixel (wave + 1 + ro, 4 j4 + kq + 1 + co); dY (row 2 wave + a, parity b, column 4 j4 + kq)
+  const int xb = (wave * UW_HW + kq) * XP + m;
+  const int yb = ((2 * wave) * 2 * UW_TW + kq) * COW + m;
+
+  f32x4 rx[X_IT], ry[Y_IT];
+  unsigned xvalid = 0;
+  auto issue_loads = [&](int tile) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+    const int sy0 = ty * UW_TH - 1, sx0 = tx * UW_TW - 1;
+    xvalid = 0;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int pix = px0 + it * (256 / QX);
+      const int hy = pix / UW_HW, hx = pix - hy * UW_HW;
+      const int sy = sy0 + hy, sx = sx0 + hx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pix < UW_HH * UW_HW && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws) {
+        v = *reinterpret_cast<const f32x4*>(a.src0 + (((size_t)b * Hs + sy) * Ws + sx) * CIW + 4 * qx);
+        xvalid |= 1u << it;
+      }
+      rx[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int pix = py0 + it * (256 / QY);                      // (row, column) of the 8 x 64 output tile
+      const int oy = 2 * ty * UW_TH + pix / (2 * UW_TW), ox = 2 * tx * UW_TW + pix % (2 * UW_TW);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oy < a.Ho && ox < a.Wo) v = *reinterpret_cast<const f32x4*>(a.dy + (((size_t)b * a.Ho + oy) * a.Wo + ox) * COW + 4 * qy);
+      ry[it] = v;
+    }
+  };
+
+  if (ks < a.T) issue_loads(ks);
+  for (int tile = ks; tile < a.T; tile += a.ksplit) {
+    __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int pix = px0 + it * (256 / QX);
+      if (pix < UW_HH * UW_HW) {
+        f32x4 v = rx[it];
+        if (tf && ((xvalid >> it) & 1u)) {   // the producer's BatchNorm + ReLU; padding stays zero
+          v = v * x_sc + x_sh;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = v[k] < 0.f ? 0.f : v[k];
+        }
+        *reinterpret_cast<f32x4*>(lx + pix * XP + 4 * qx) = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < Y_IT; ++it) {
+      const int pix = py0 + it * (256 / QY);
+      const int row = pix / (2 * UW_TW), col = pix % (2 * UW_TW);
+      *reinterpret_cast<f32x4*>(ly + ((row * 2 + (col & 1)) * UW_TW + (col >> 1)) * COW + 4 * qy) = ry[it];
+    }
+    __syncthreads();
+    if (tile + a.ksplit < a.T) issue_loads(tile + a.ksplit);
+
+#pragma unroll 2
+    for (int j4 = 0; j4 < UW_TW / 4; ++j4) {
+      float bv[2][2], av[3][3][CIT];
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) bv[pa][pb] = ly[yb + ((pa * 2 + pb) * UW_TW + 4 * j4) * COW];
+#pragma unroll
+      for (int ro = 0; ro < 3; ++ro)
+#pragma unroll
+        for (int co = 0; co < 3; ++co)
+#pragma unroll
+          for (int i = 0; i < CIT; ++i) av[ro][co][i] = lx[xb + (ro * UW_HW + 4 * j4 + co) * XP + 16 * i];
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+              for (int i = 0; i < CIT; ++i)
+                acc[pa][pb][dy][dx][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pa + dy][pb + dx][i], bv[pa][pb],
+                                                                              acc[pa][pb][dy][dx][i], 0, 0, 0);
+    }
+  }
+  // ---- fold to the nine taps (fixed order) and write this (k-split, wave)'s slab: D row = ci 4 kq + r, column = co m
+  const int part = ks * 4 + wave;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      // tap row kh lies in R(a, dy) for: kh 0 -> (0,0), (1,0); kh 1 -> (0,1), (1,0); kh 2 -> (0,1), (1,1)
+      const int a0 = kh == 0 ? 0 : (kh == 1 ? 0 : 0), d0 = kh == 0 ? 0 : 1;
+      const int a1 = 1, d1 = kh == 2 ? 1 : 0;
+      const int b0 = 0, e0 = kw == 0 ? 0 : 1;
+      const int b1 = 1, e1 = kw == 2 ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < CIT; ++i) {
+        const f32x4 v = (acc[a0][b0][d0][e0][i] + acc[a0][b1][d0][e1][i]) + (acc[a1][b0][d1][e0][i] + acc[a1][b1][d1][e1][i]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          a.ws[(((size_t)part * 9 + kh * 3 + kw) * CIW + 16 * i + 4 * kq + r) * COW + m] = v[r];
+      }
+    }
+}
+
+static bool nl_upc_enabled();
+static int wg_upc(const dt_conv_desc* d) {   // 1: the sub-pixel weight-gradient kernel takes this (n16-supported) layer
+  static const int on = [] {
+    const char* e = getenv("DT_FP32_SUBPIXEL_WGRAD");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  return on && nl_upc_enabled() && d->mode0 == 1 && d->C1 == 0 && (d->C0 == 16 || d->C0 == 32) && d->Cout == 16 &&
+         ((d->Hin | d->Win) & 1) == 0 && d->Ho == d->Hin && d->Wo == d->Win && d->Win >= 64;
+}
+
 int dt_wgrad_n16_cfg(const dt_conv_desc* d, int* ksplit, int* parts) {
-  const int T = d->B * dt_cdiv(d->Ho, W16_TH) * dt_cdiv(d->Wo, W16_TW);
+  const int T = wg_upc(d) ? d->B * dt_cdiv(d->Hin / 2, UW_TH) * dt_cdiv(d->Win / 2, UW_TW)
+                          : d->B * dt_cdiv(d->Ho, W16_TH) * dt_cdiv(d->Wo, W16_TW);
   int ks = 512;
   if (ks > T) ks = T;
   *ksplit = ks;
@@ -363,6 +523,15 @@ int dt_wgrad_n16_launch(const dt_conv_desc* d, const float* src0, const float* d
   a.tiles_x = dt_cdiv(d->Wo, W16_TW); a.tiles_y = dt_cdiv(d->Ho, W16_TH);
   int parts;
   a.T = dt_wgrad_n16_cfg(d, &a.ksplit, &parts);
+  if (wg_upc(d)) {
+    a.tiles_x = dt_cdiv(d->Win / 2, UW_TW); a.tiles_y = dt_cdiv(d->Hin / 2, UW_TH);
+    if (d->C0 == 16)
+      hipLaunchKernelGGL((conv3x3_wgrad_f32_upc_kernel<1>), dim3(a.ksplit), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv3x3_wgrad_f32_upc_kernel<2>), dim3(a.ksplit), dim3(256), 0, st, a);
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
   const int cit = d->C0 > 16 ? 2 : 1, cot = d->Cout > 16 ? 2 : 1;
   if (cit == 1 && cot == 1)
     hipLaunchKernelGGL((conv_wgrad_n16_kernel<1, 1>), dim3(a.ksplit), dim3(256), 0, st, a);

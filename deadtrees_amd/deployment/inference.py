@@ -20,6 +20,11 @@ from .. import ops
 class Inference:
     """reference deployment/inference.py:14-27"""
 
+    @property
+    def in_channels(self):
+        """band planes the network reads (infer_tile copies only these to the device); None while unknown"""
+        return getattr(self, "_channels", None)
+
     def __init__(self, model_file: Union[str, Path]) -> None:
         self._model_file = model_file if isinstance(model_file, Path) else Path(model_file)
 
@@ -128,6 +133,7 @@ class GraphedTilePredictor:
 
     def __init__(self, model, in_channels: int = 3, precision: str = "fp32"):
         self.model, self.c, self.precision = model, in_channels, precision
+        self.in_channels = in_channels
         self._graphs = {}
 
     def _eager(self, tiles_u8):

@@ -173,9 +173,24 @@ class Tiler:
         self._target.rio.to_raster(outfile, compress="LZW", tiled=True)
 
 
+def infer_rasters(inference, rasters, subtile: int = 256, batch_size: int = 64, rank: int = 0, world: int = 1,
+                  device: str = "cuda", tile_shape: Optional[Tuple[int, int]] = None, skip_blank: bool = True):
+    """the directory loop of scripts/inference.py:71-115 over in-memory rasters (GeoTIFF I/O needs rioxarray, absent
+    here): ``rasters`` yields ``array`` or ``(key, array)``; rank r of ``world`` takes rasters r, r + world, ... (tiles are
+    independent: no collective).  Yields ``(key, class_map)`` in input order of the rank's share; rasters whose band 1
+    holds only 0 / 255 (``is_valid_tile``, :60-62) are skipped like the reference does — ``(key, None)`` — without a
+    forward pass (device reduction over the uploaded raster, ``ops.band_has_data``)."""
+    for i, item in enumerate(rasters):
+        if i % world != rank:
+            continue
+        key, arr = item if isinstance(item, tuple) else (i, item)
+        yield key, infer_tile(inference, arr, subtile=subtile, batch_size=batch_size, device=device, tile_shape=tile_shape,
+                              skip_blank=skip_blank)
+
+
 def infer_tile(inference, arr_chw_u8: np.ndarray, subtile: int = 256, batch_size: int = 64, rank: int = 0,
                world: int = 1, device: str = "cuda", group=None, tile_shape: Optional[Tuple[int, int]] = None,
-               on_device: Optional[bool] = None) -> np.ndarray:
+               on_device: Optional[bool] = None, skip_blank: bool = False) -> Optional[np.ndarray]:
     """whole-tile inference of scripts/inference.py:80-115 on the MI355X path: split -> (uint8 H2D, normalise on the
     device) -> forward + fused argmax -> uint8 D2H -> merge.  With world > 1 the sub-tile batches j = rank (mod world)
     are processed locally and the uint8 class maps are all-gathered (no other collective: tiles are independent).
@@ -193,7 +208,9 @@ def infer_tile(inference, arr_chw_u8: np.ndarray, subtile: int = 256, batch_size
     if on_device:
         if world != 1:
             raise ValueError("infer_tile: the on-device split / merge is the single-rank form")
-        return _infer_tile_on_device(inference, arr_chw_u8, subtile, batch_size, device, tile_shape)
+        return _infer_tile_on_device(inference, arr_chw_u8, subtile, batch_size, device, tile_shape, skip_blank)
+    if skip_blank and bool(np.isin(arr_chw_u8[0], [0, 255]).all()):    # scripts/inference.py:60-62 is_valid_tile
+        return None
     t = Tiler(tile_shape=tile_shape, subtile_shape=(subtile, subtile))
     t.load_array(arr_chw_u8)
     used = t.get_batches()
@@ -216,7 +233,7 @@ def infer_tile(inference, arr_chw_u8: np.ndarray, subtile: int = 256, batch_size
 
 
 def _infer_tile_on_device(inference, arr_chw_u8: np.ndarray, subtile: int, batch_size: int, device: str,
-                          tile_shape: Tuple[int, int]) -> np.ndarray:
+                          tile_shape: Tuple[int, int], skip_blank: bool = False) -> Optional[np.ndarray]:
     """single-rank form of ``infer_tile`` with the block split / merge on the device: ONE uint8 H2D copy of the raster, the
     sub-tiles of ``Tiler.get_batches`` (same ones, same row-major order: the [0:ceil(h/d), 0:ceil(w/d)] blocks of the
     zero-padded tile, reference tiler.py:121-134 + utils/data_handling.py:9-20) as a strided view -> NHWC uint8 batches
@@ -228,7 +245,14 @@ def _infer_tile_on_device(inference, arr_chw_u8: np.ndarray, subtile: int, batch
     if tile_shape[0] % d or tile_shape[1] % d:
         raise ValueError(f"Shapes unaligned: {tuple(tile_shape)} / {d}")
     nby, nbx = -(-h // d), -(-w // d)
+    nch = int(getattr(inference, "in_channels", C) or C)
+    if 0 < nch < C:                 # band planes the network never reads (N of an RGBN raster under an RGB model) stay on the host
+        arr_chw_u8, C = arr_chw_u8[:nch], nch
     x = torch.from_numpy(np.ascontiguousarray(arr_chw_u8)).to(device, non_blocking=True)
+    if skip_blank:
+        from .. import ops
+        if int(ops.band_has_data(x[0])) == 0:       # is_valid_tile on the uploaded raster: nothing but 0 / 255 in band 1
+            return None
     if hasattr(inference, "run_blocks"):
         # round 3: split + zero padding + Normalize + NHWC in one gather per batch (dt_split_normalize_u8), no ATen passes
         outs = [inference.run_blocks(x, d, j, min(batch_size, nby * nbx - j)) for j in range(0, nby * nbx, batch_size)]
@@ -239,6 +263,6 @@ def _infer_tile_on_device(inference, arr_chw_u8: np.ndarray, subtile: int, batch
             x = xp
         blocks = x.view(C, nby, d, nbx, d).permute(1, 3, 2, 4, 0).contiguous().view(nby * nbx, d, d, C)
         outs = [inference.run_u8(blocks[j:j + batch_size], device=device) for j in range(0, nby * nbx, batch_size)]
-    maps = torch.cat(outs, dim=0).to(torch.uint8)
+    maps = (outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)).to(torch.uint8)
     merged = maps.view(nby, nbx, d, d).permute(0, 2, 1, 3).reshape(nby * d, nbx * d)
     return merged[:h, :w].contiguous().cpu().numpy()

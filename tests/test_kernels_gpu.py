@@ -146,6 +146,27 @@ def test_conv_stride2_small_maps_share_a_tile(B, h, w_, Cin, Cout):
     assert torch.equal(y1[0], y[B - 1])
 
 
+@pytest.mark.parametrize("h,w_,Cin,tf", [(20, 36, 32, True), (21, 33, 32, False), (64, 64, 16, True), (5, 40, 16, False), (4, 32, 32, True)])
+def test_conv_upsampled_wgrad_subpixel(h, w_, Cin, tf):
+    """dec.4.conv1 weight gradient in its sub-pixel form (conv3x3_wgrad_f32_upc_kernel: 16 products per source pixel folded
+    to the nine taps) against float64 autograd of conv3x3(interpolate(x, 2, nearest)): ragged maps, borders, with and
+    without the producer's BatchNorm + ReLU applied while staging"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(277 + h)
+    B, Cout = 3, 16
+    yraw = torch.randn((B, Cin, h, w_), generator=g)
+    sc = 1 + 0.3 * torch.randn(Cin, generator=g)
+    sh = 0.2 * torch.randn(Cin, generator=g) + 0.3
+    wt = (torch.randn((Cout, Cin, 3, 3), generator=g) * 0.07).double().requires_grad_(True)
+    x = F.relu(yraw.double() * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]) if tf else yraw.double()
+    out = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, padding=1)
+    dy = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dy)
+    dw = ops.conv2d_wgrad(nhwc(yraw), nhwc(dy), 3, 1, 1, mode0=1, in_scale=sc.to(DEV) if tf else None,
+                          in_shift=sh.to(DEV) if tf else None)
+    assert rel_err(dw.cpu().permute(3, 2, 0, 1), wt.grad) < 3e-6
+
+
 @pytest.mark.parametrize("k,s,p,Cin,Cout,h,w_,relu,C1,up", [
     (7, 2, 3, 3, 64, 64, 96, True, 0, False),      # stem
     (7, 2, 3, 4, 64, 37, 41, True, 0, False),      # RGBN stem, ragged

@@ -452,3 +452,22 @@ def test_blank_raster_flag_and_nhwc_entry():
     no_blocks = infer_tile(_Old(), raster, subtile=128, batch_size=4, device=DEV)
     host = infer_tile(_Inf(), raster, subtile=128, batch_size=4, device=DEV, on_device=False)
     assert on_dev.shape == (200, 330) and np.array_equal(on_dev, host) and np.array_equal(no_blocks, host)
+
+    # the directory loop of scripts/inference.py:71-115 over in-memory rasters: blank rasters (band 1 all 0 / 255) are
+    # skipped without a forward pass, the others give infer_tile's map; an inference object that reads 3 band planes gets
+    # only those uploaded (same map); rank r of 2 takes every second raster
+    from deadtrees_amd.deployment.tiler import infer_rasters
+
+    class _Rgb(_Inf):
+        in_channels = 3
+
+    blank = raster.copy()
+    blank[0] = np.where(blank[0] > 127, 255, 0)
+    queue = [("a", raster), ("blank", blank), ("c", raster[:, :128, :256])]
+    got = dict(infer_rasters(_Rgb(), queue, subtile=128, batch_size=4, device=DEV))
+    assert list(got) == ["a", "blank", "c"] and got["blank"] is None
+    assert np.array_equal(got["a"], host) and got["c"].shape == (128, 256)
+    assert infer_tile(_Inf(), blank, subtile=128, batch_size=4, device=DEV, on_device=False, skip_blank=True) is None
+    assert infer_tile(_Inf(), blank, subtile=128, batch_size=4, device=DEV) is not None      # the filter is opt-in here
+    r1 = dict(infer_rasters(_Rgb(), queue, subtile=128, batch_size=4, device=DEV, rank=1, world=2))
+    assert list(r1) == ["blank"]
