@@ -111,6 +111,8 @@ SIGNATURES = {
     "dt_conv2d_upsampled_dgrad_supported": (C.c_int, [_P]),
     "dt_conv2d_upsampled_dgrad_rows": (C.c_int, [_P]),
     "dt_conv2d_upsampled_dgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
+    "dt_conv2d_bf16_upsampled_dgrad_supported": (C.c_int, [_P]),
+    "dt_conv2d_bf16_upsampled_dgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_upsample2x_bwd_bn_bf16_rows": (C.c_int, [C.c_int] * 4),
     "dt_upsample2x_bwd_bn_bf16": (C.c_int, [c_f, c_f, C.POINTER(BnBwdFuse), c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_stem_s2d_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

@@ -35,7 +35,7 @@ int dt_wgrad_bf16_dma_launch(const dt_conv_desc* d, const void* src0, const void
 int dt_conv_bf16_narrow_supported(const dt_conv_desc* d);
 int dt_conv_bf16_narrow_grid(const dt_conv_desc* d, int tf, int bnb);   // persistent workgroups of the variant
 int dt_conv_bf16_narrow_rows(const dt_conv_desc* d);                    // rows of the statistics buffer (>= any grid)
-int dt_conv_bf16_narrow_launch(const dt_conv_desc* d, ConvBfArgs a, hipStream_t st);
+int dt_conv_bf16_narrow_launch(const dt_conv_desc* d, ConvBfArgs a, hipStream_t st, bool upsample_bwd = false);
 int dt_wgrad_bf16_narrow_supported(const dt_conv_desc* d);
 size_t dt_wgrad_bf16_narrow_workspace(const dt_conv_desc* d);
 int dt_wgrad_bf16_narrow_launch(const dt_conv_desc* d, const void* src0, const void* dy, float* ws, const float* in_scale,

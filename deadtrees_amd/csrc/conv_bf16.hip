@@ -513,6 +513,35 @@ extern "C" int dt_conv2d_bf16_bn_bwd(const dt_conv_desc* d, const void* src0, co
   return conv2d_bf16_impl(d, src0, nullptr, w_bf16, out, nullptr, red, nullptr, nullptr, stream, fuse);
 }
 
+// data gradient of a convolution whose input was a nearest x2 up-sampling, for the narrow layers (dec4.conv1): `d`, src0 =
+// dy and w_bf16 as for dt_conv2d_bf16_bn_bwd (the full-resolution data-gradient form); the 2x2 sums of the up-sampling's
+// backward are taken on the accumulators and gx [B, Ho/2, Wo/2, Cout] is stored with the BatchNorm-backward sums of the
+// layer below in red (P = dt_conv2d_bf16_stat_rows(d)) — replaces dt_conv2d_bf16 + dt_upsample2x_bwd_bn_bf16
+extern "C" int dt_conv2d_bf16_upsampled_dgrad_supported(const dt_conv_desc* d) {
+  static const int on = [] {
+    const char* e = getenv("DT_BF16_FUSE_UPSAMPLE_BWD");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  return on && d != nullptr && bf_validate(d) == DT_OK && dt_conv_bf16_narrow_supported(d) && d->mode0 == 0 &&
+         ((d->Ho | d->Wo) & 1) == 0;
+}
+
+extern "C" int dt_conv2d_bf16_upsampled_dgrad(const dt_conv_desc* d, const void* dy, const void* w_bf16, void* gx, float* red,
+                                              const dt_bn_bwd_fuse* fuse, void* stream) {
+  DT_REQUIRE(d && dy && w_bf16 && gx && red && fuse && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale &&
+                 fuse->act_shift && fuse->act == nullptr, "conv_bf16_upsampled_dgrad: null pointer / stored activation");
+  DT_REQUIRE(dt_conv2d_bf16_upsampled_dgrad_supported(d), "conv_bf16_upsampled_dgrad: layer shape not supported");
+  ConvBfArgs a;
+  a.bnb = *fuse;
+  a.out1 = nullptr; a.stats = red; a.cout_split = 0; a.accumulate = 0;
+  a.src0 = (const __bf16*)dy; a.src1 = nullptr; a.w = (const __bf16*)w_bf16;
+  a.in_scale = nullptr; a.in_shift = nullptr; a.out = (__bf16*)gx;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = 0; a.mode0 = 0;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout; a.pad = d->pad;
+  a.n_tiles = 1;
+  return dt_conv_bf16_narrow_launch(d, a, (hipStream_t)stream, true);
+}
+
 static int conv2d_bf16_impl(const dt_conv_desc* d, const void* src0, const void* src1, const void* w_bf16, void* out,
                             void* out1, float* stats, const float* in_scale, const float* in_shift, void* stream,
                             const dt_bn_bwd_fuse* fuse) {

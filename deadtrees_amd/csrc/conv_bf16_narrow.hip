@@ -53,8 +53,13 @@ __device__ __forceinline__ float nr_swap_pair(float v) {   // the value of the l
 
 // CB = Cin / 16, NB = Cout / 16 (1 or 2 each); TF: BatchNorm + ReLU of the producer applied while staging;
 // BNB: fused BatchNorm-backward sums of the layer the written gradient belongs to (virtual activation)
-template <int CB, int NB, bool TF, bool BNB>
+// UPB (with BNB): the convolution's input was a nearest x2 up-sampling (dec4.conv1's data gradient) — the 2x2 sums of its
+// backward are taken on the fp32 accumulators (row pair = two M blocks of the wave, column pair = two registers of the
+// lane) and the LOW-resolution gradient [B, Ho/2, Wo/2, COUT] is stored, with the sums of the layer below: the
+// full-resolution gradient (1 GB written and read back per 64-tile step) and the dt_upsample2x_bwd_bn_bf16 pass disappear
+template <int CB, int NB, bool TF, bool BNB, bool UPB = false>
 __global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : (CB == 1 && NB == 1 ? 4 : 3)) void conv3x3_bf16_narrow_kernel(const ConvBfArgs a, const int total_tiles) {
+  static_assert(!UPB || BNB, "the up-sample backward form carries the BatchNorm-backward sums");
   using G = NrGeom<CB, NB>;
   constexpr int CIN = 16 * CB, COUT = 16 * NB;
   __shared__ __attribute__((aligned(16))) unsigned char lds[NR_PIX * G::PITCH + 256 * G::OUTP];
@@ -219,6 +224,22 @@ __global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : (CB == 1 && NB == 1
       }
     }
     // pack channel pairs (n, n + 1) across the lane pair and write the bf16 tile [pixel][channel] to the staging image
+    if constexpr (UPB) {
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int mbx = 0; mbx < 2; ++mbx)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          // source pixel (row wave, column 8 mbx + 2 kg + ip) = rows 2 wave, 2 wave + 1 x columns 2 ip, 2 ip + 1 of the block
+          const float x0 = (acc[mbx][nb][0] + acc[mbx][nb][1]) + (acc[mbx + 2][nb][0] + acc[mbx + 2][nb][1]);
+          const float x1 = (acc[mbx][nb][2] + acc[mbx][nb][3]) + (acc[mbx + 2][nb][2] + acc[mbx + 2][nb][3]);
+          const float y0 = nr_swap_pair(x0), y1 = nr_swap_pair(x1);
+          const float lo = odd ? y1 : x0, hi = odd ? x1 : y0;
+          const bf16x2 pk = {(__bf16)lo, (__bf16)hi};
+          const int pl = wave * (NR_TW / 2) + 8 * mbx + 2 * kg + (odd ? 1 : 0);
+          *reinterpret_cast<bf16x2*>(lds_out + pl * G::OUTP + 2 * (16 * nb + (m & ~1))) = pk;
+        }
+    } else
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -235,13 +256,17 @@ __global__ __launch_bounds__(256, (CB == 2 && NB == 2) ? 2 : (CB == 1 && NB == 1
           *reinterpret_cast<bf16x2*>(lds_out + pl * G::OUTP + 2 * (16 * nb + (m & ~1))) = pk;
         }
     __syncthreads();   // barrier C: the staging image is complete; every wave is done with the input image
+    // UPB: 4 x 16 source pixels (one pass, threads beyond 64 SEGS idle); else the 8 x 32 tile in SEGS passes
+    constexpr int OW = UPB ? NR_TW / 2 : NR_TW, OPIX = UPB ? NR_TW * NR_TH / 4 : NR_TW * NR_TH;
+    const int oh_ = UPB ? (a.Ho >> 1) : a.Ho, ow_ = UPB ? (a.Wo >> 1) : a.Wo;
+    const int py0 = UPB ? (oy0 >> 1) : oy0, px0 = UPB ? (ox0 >> 1) : ox0;
 #pragma unroll
-    for (int it = 0; it < G::SEGS; ++it) {
+    for (int it = 0; it < (OPIX + PER_IT - 1) / PER_IT; ++it) {
       const int pl = prow + it * PER_IT;
-      const int oy = oy0 + pl / NR_TW, ox = ox0 + pl % NR_TW;
-      if (interior || (oy < a.Ho && ox < a.Wo)) {
+      const int oy = py0 + pl / OW, ox = px0 + pl % OW;
+      if ((OPIX % PER_IT == 0 || pl < OPIX) && ((!UPB && interior) || (oy < oh_ && ox < ow_))) {
         const u32x4 raw = *reinterpret_cast<const u32x4*>(lds_out + pl * G::OUTP + 16 * sg);
-        const size_t o = (((size_t)b * a.Ho + oy) * a.Wo + ox) * COUT + 8 * sg;
+        const size_t o = (((size_t)b * oh_ + oy) * ow_ + ox) * COUT + 8 * sg;
         *reinterpret_cast<u32x4*>(a.out + o) = raw;
         if constexpr (BNB) {   // virtual activation — the arithmetic of bn_bwd_reduce_bf16_kernel / conv_bf16_dma.hip
           const u32x4 yraw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(a.bnb.y) + o);
@@ -341,17 +366,18 @@ static int nr_occupancy(K kernel) {
 }
 
 template <int CB, int NB>
-static int nr_occ_of(bool tf, bool bnb) {
-  static int cache[3] = {0, 0, 0};
-  const int v = tf ? 1 : (bnb ? 2 : 0);
+static int nr_occ_of(bool tf, int bnb) {   // bnb: 0 none, 1 fused BatchNorm-backward sums, 2 with the up-sample backward
+  static int cache[4] = {0, 0, 0, 0};
+  const int v = tf ? 1 : (bnb ? 1 + bnb : 0);
   if (cache[v] == 0)
     cache[v] = tf ? nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, true, false>)
-                  : (bnb ? nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, false, true>)
-                         : nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, false, false>));
+                  : (bnb == 2 ? nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, false, true, true>)
+                     : bnb  ? nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, false, true>)
+                            : nr_occupancy(conv3x3_bf16_narrow_kernel<CB, NB, false, false>));
   return cache[v];
 }
 
-static int nr_per_cu(const dt_conv_desc* d, bool tf, bool bnb) {
+static int nr_per_cu(const dt_conv_desc* d, bool tf, int bnb) {
   if (d->C0 == 16 && d->Cout == 16) return nr_occ_of<1, 1>(tf, bnb);
   if (d->C0 == 16) return nr_occ_of<1, 2>(tf, bnb);
   if (d->Cout == 16) return nr_occ_of<2, 1>(tf, bnb);
@@ -366,23 +392,27 @@ int dt_conv_bf16_narrow_rows(const dt_conv_desc* d) {
 }
 
 int dt_conv_bf16_narrow_grid(const dt_conv_desc* d, int tf, int bnb) {
-  const int t = nr_tiles(d), per_cu = nr_per_cu(d, tf != 0, bnb != 0);
+  const int t = nr_tiles(d), per_cu = nr_per_cu(d, tf != 0, bnb);
   return t < per_cu * NR_CUS ? t : per_cu * NR_CUS;
 }
 
 template <int CB, int NB>
-static int nr_launch(const ConvBfArgs& a, int grid, int total, bool tf, bool bnb, hipStream_t st) {
+static int nr_launch(const ConvBfArgs& a, int grid, int total, bool tf, int bnb, hipStream_t st) {
   const dim3 g((unsigned)grid), blk(256);
   if (tf && bnb) return DT_EINVAL;
   if (tf) hipLaunchKernelGGL((conv3x3_bf16_narrow_kernel<CB, NB, true, false>), g, blk, 0, st, a, total);
+  else if (bnb == 2) hipLaunchKernelGGL((conv3x3_bf16_narrow_kernel<CB, NB, false, true, true>), g, blk, 0, st, a, total);
   else if (bnb) hipLaunchKernelGGL((conv3x3_bf16_narrow_kernel<CB, NB, false, true>), g, blk, 0, st, a, total);
   else hipLaunchKernelGGL((conv3x3_bf16_narrow_kernel<CB, NB, false, false>), g, blk, 0, st, a, total);
   return DT_OK;
 }
 
-int dt_conv_bf16_narrow_launch(const dt_conv_desc* d, ConvBfArgs a, hipStream_t st) {
+int dt_conv_bf16_narrow_launch(const dt_conv_desc* d, ConvBfArgs a, hipStream_t st, bool upsample_bwd) {
   DT_REQUIRE(dt_conv_bf16_narrow_supported(d), "conv_bf16_narrow: layer shape not supported");
-  const bool tf = a.in_scale != nullptr, bnb = a.bnb.y != nullptr;
+  const bool tf = a.in_scale != nullptr;
+  const int bnb = a.bnb.y != nullptr ? (upsample_bwd ? 2 : 1) : 0;
+  DT_REQUIRE(!upsample_bwd || (bnb == 2 && ((d->Ho | d->Wo) & 1) == 0),
+             "conv_bf16_narrow: the up-sample backward form needs the fused sums and an even map");
   DT_REQUIRE(!bnb || (a.bnb.act == nullptr && a.bnb.act_scale && a.bnb.act_shift && a.stats),
              "conv_bf16_narrow: the fused BatchNorm-backward sums take a virtual activation (scale / shift) and a stats buffer");
   DT_REQUIRE(!(tf && bnb), "conv_bf16_narrow: no input transform on the BatchNorm-backward form");

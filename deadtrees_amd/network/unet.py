@@ -1111,6 +1111,32 @@ class UNetEngine:
             x_ss = self._ss(sp.decoder[i - 1].conv2, bnws) if d["x_virtual"] else None
             wgrad(blk.conv1, d["x"], d["skip"], 1, Hh, Ww, dy1, in_ss=x_ss)
             cx = blk.in_ch
+            if d["skip"] is None and i >= 1:
+                # dec4.conv1: data gradient, the 2x2 sums of the up-sampling's backward and the BatchNorm-backward sums of
+                # the block below in one launch of the narrow kernel — no full-resolution gradient tensor
+                c1 = blk.conv1
+                ddesc = self._desc(B, Hh, Ww, c1.cout, 0, 0, Hh, Ww, c1.cin, c1.k, 1, c1.k - 1 - c1.pad, 0, 0)
+                if lib.dt_conv2d_bf16_upsampled_dgrad_supported(C.byref(ddesc)):
+                    pb = sp.decoder[i - 1].conv2
+                    y2p = S[f"D{i - 1}"]["y2"]
+                    P = lib.dt_conv2d_bf16_stat_rows(C.byref(ddesc))
+                    red = self._buf("bn_red_up", lib.dt_bn_stats_floats(P, cx), device=dev)
+                    psc, psh = self._ss(pb, bnws)
+                    fuse = _lib.BnBwdFuse(_p(y2p), _p(bnws[pb.bn_off:pb.bn_off + cx]),
+                                          _p(bnws[nb + pb.bn_off:nb + pb.bn_off + cx]), _p(psc), _p(psh))
+                    g = torch.empty(d["x"].shape, dtype=bf, device=dev)
+                    ev = self._pb()
+                    _lib.check(lib.dt_conv2d_bf16_upsampled_dgrad(C.byref(ddesc), _p(dy1), _p(wbd[c1.w_off:c1.w_off + c1.w_size]),
+                                                                  _p(g), _p(red), C.byref(fuse), st),
+                               "dt_conv2d_bf16_upsampled_dgrad")
+                    self._pe(ev, f"conv3x3_bf16_narrow_kernel<{c1.cout // 16}, {c1.cin // 16}, false, true, true>",
+                             2.0 * 9 * c1.cin * c1.cout * Hh * Ww * B,
+                             2.0 * B * (Hh * Ww * c1.cout + (Hh // 2) * (Ww // 2) * cx * 2))
+                    g_red = (red, P)
+                    del dy1
+                    self._tr(f"D{i}.g", g)
+                    S[f"D{i}"] = None
+                    continue
             dup = torch.empty((B, Hh, Ww, cx), dtype=bf, device=dev)
             if d["skip"] is not None:
                 dskip = torch.empty(d["skip"].shape, dtype=bf, device=dev)

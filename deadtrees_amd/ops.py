@@ -448,6 +448,25 @@ def conv2d_bf16_bn_bwd(src0, w_packed, cout, y, mean, invstd, act_scale=None, ac
     return out, red[:2 * P * cout].view(2, P, cout)
 
 
+def conv2d_bf16_upsampled_dgrad(dy, w_packed_dgrad, cin, y, mean, invstd, act_scale, act_shift):
+    """bf16 gradient of x for out = conv3x3(nearest_upsample_x2(x)) from dy [B,2h,2w,cout] (bf16) and the data-gradient
+    weight image (pack_weights_bf16(..., dgrad=True)), the narrow layers only: the 2x2 sums are taken on the fp32
+    accumulators -> (gx [B,h,w,cin] bf16, red [2,P,cin] = BatchNorm-backward partial sums of the layer with raw output y)"""
+    _gpu(dy, w_packed_dgrad, y, mean, invstd, act_scale, act_shift)
+    lib = _lib.load()
+    B, H, W, cout = dy.shape
+    d = conv_desc(B, H, W, cout, 0, 0, cin, 3, 1, 1)
+    if not lib.dt_conv2d_bf16_upsampled_dgrad_supported(C.byref(d)):
+        raise ValueError("conv2d_bf16_upsampled_dgrad: layer shape not covered by the narrow kernel")
+    P = lib.dt_conv2d_bf16_stat_rows(C.byref(d))
+    red = torch.empty(lib.dt_bn_stats_floats(P, cin), dtype=torch.float32, device=dy.device)
+    gx = torch.empty((B, H // 2, W // 2, cin), dtype=torch.bfloat16, device=dy.device)
+    fuse = _lib.BnBwdFuse(_p(y.contiguous()), _p(mean), _p(invstd), _p(act_scale), _p(act_shift))
+    _lib.check(lib.dt_conv2d_bf16_upsampled_dgrad(C.byref(d), _p(dy.contiguous()), _p(w_packed_dgrad), _p(gx), _p(red),
+                                                  C.byref(fuse), _st()), "dt_conv2d_bf16_upsampled_dgrad")
+    return gx, red[:2 * P * cin].view(2, P, cin)
+
+
 def upsample2x_bwd_bn(dup, y, mean, invstd, act_scale, act_shift):
     """2x2-sum backward of a nearest x2 upsample + the BatchNorm-backward partial sums of the layer with raw output
     `y` ([B,H,W,C], fp32 or bf16 like dup) -> (dx, red [2,P,C])"""

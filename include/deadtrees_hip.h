@@ -404,6 +404,17 @@ int dt_stem_unpack_wgrad(const float* dw4, float* dw_hwio_7x7, int Cin, int Cout
 int dt_conv2d_bf16_bn_bwd(const dt_conv_desc* desc, const void* src0, const void* w_bf16, void* out, float* red,
                           const dt_bn_bwd_fuse* fuse, void* stream);
 
+/* bf16: data gradient of y = conv3x3(nearest_upsample_x2(x)) for the narrow decoder layer in ONE launch: `desc`, dy and
+ * w_bf16 as for dt_conv2d_bf16_bn_bwd (the full-resolution data-gradient form, plain store); the 2x2 sums of the
+ * up-sampling's backward are taken on the fp32 accumulators, gx [B, Ho/2, Wo/2, Cout] (bf16) is stored and red
+ * [2][P][Cout], P = dt_conv2d_bf16_stat_rows(desc), receives the BatchNorm-backward sums of the layer that produced x
+ * (fuse: its bf16 raw output at gx's resolution, mean, invstd, act_scale / act_shift) like dt_upsample2x_bwd_bn_bf16
+ * — which it replaces together with the full-resolution dt_conv2d_bf16 launch (reference: autograd of
+ * F.interpolate(nearest, x2) + Conv2d under AMP, smp unet/decoder.py DecoderBlock.forward via segmodel.py:30-57). */
+int dt_conv2d_bf16_upsampled_dgrad_supported(const dt_conv_desc* desc);
+int dt_conv2d_bf16_upsampled_dgrad(const dt_conv_desc* desc, const void* dy, const void* w_bf16, void* gx, float* red,
+                                   const dt_bn_bwd_fuse* fuse, void* stream);
+
 /* Nearest x2 upsample backward (2x2 sums, like dt_upsample2x_bwd) with the BatchNorm-backward reduction of the layer
  * whose (virtual) activation was upsampled fused in: dx[B,H,W,C] is that layer's output gradient, fuse->y its raw
  * output; red[2][P][C], P = dt_upsample2x_bwd_bn_rows(...), holds dt_bn_stats_floats(P, C) floats -> dt_bn_bwd_apply.

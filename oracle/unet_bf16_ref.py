@@ -23,7 +23,9 @@ backward
     sums over the bf16 gradient; ``dy = bf16(gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)))``;
   * data gradients: bf16 dy x bf16 weights, wide accumulation, ONE rounding at the store; gradient joins
     add the bf16 value already in memory to the unrounded accumulator and round once;
-  * nearest-upsample backward: (a+b)+(c+d) of bf16 values, one rounding; max-pool backward joins likewise;
+  * nearest-upsample backward: (a+b)+(c+d) of bf16 values, one rounding; max-pool backward joins likewise; the
+    narrow decoder block without a skip (dec4, channels 16 / 32, maps >= 8 x 32) sums the UNROUNDED data-gradient
+    accumulators instead and rounds once (round 3: one kernel, dt_conv2d_bf16_upsampled_dgrad);
   * weight gradients: bf16 operands (the staged, rounded activation), wide accumulation, fp32 result.
 
 Two ways to use it (tests/test_bf16_gpu.py):
@@ -245,8 +247,19 @@ class Bf16TrainOracle:
             dy1, _ = self._bn_bwd(blk.conv1[1], f"{p}.conv1.1", dz1, d["y1"], d["ss1"], virtual=True)
             dy1 = self._t(f"{n}.dy1", dy1)
             self._wgrad(blk.conv1[0], f"{p}.conv1.0.weight", d["xin"], dy1)
-            dxin = rbf(self._dgrad(blk.conv1[0], d["xin"].shape, dy1)).to(dt)
+            dxin_acc = self._dgrad(blk.conv1[0], d["xin"].shape, dy1)
             cx = d["cx"]
+            cv = blk.conv1[0]
+            if (dxin_acc.shape[1] == cx and i >= 1 and cv.in_channels in (16, 32) and cv.out_channels in (16, 32)
+                    and dy1.shape[3] >= 32 and dy1.shape[2] >= 8):
+                # the narrow layer without a skip (dec4.conv1): the HIP path takes the 2x2 sums of the up-sampling's backward
+                # on the fp32 accumulators of the data gradient (dt_conv2d_bf16_upsampled_dgrad) — ONE rounding, no
+                # full-resolution gradient tensor
+                u = dxin_acc.to(dt)
+                g = self._t(f"{n}.g", rbf((u[:, :, 0::2, 0::2] + u[:, :, 0::2, 1::2]) +
+                                          (u[:, :, 1::2, 0::2] + u[:, :, 1::2, 1::2])).to(dt))
+                continue
+            dxin = rbf(dxin_acc).to(dt)
             dup = self._t(f"{n}.dup", dxin[:, :cx].contiguous())
             if dxin.shape[1] > cx:
                 skip_grads[3 - i] = self._t(f"{n}.dskip", dxin[:, cx:].contiguous())

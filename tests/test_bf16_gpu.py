@@ -112,6 +112,42 @@ def test_conv_bf16_narrow_kernel_upsampled_input_and_fused_activation(C0, Cout, 
     close_bf16(to_nchw(y3), plain)
 
 
+@pytest.mark.parametrize("h,w_,Cin,Cout", [(20, 24, 32, 16), (21, 19, 32, 16), (64, 64, 16, 16), (9, 40, 16, 32), (4, 16, 32, 32)])
+def test_conv_bf16_upsampled_data_gradient_fused(h, w_, Cin, Cout):
+    """dec4.conv1 backward under AMP in one launch (the narrow kernel's up-sample-backward epilogue): gradient of x for
+    conv3x3(interpolate(x, 2, nearest)) with the 2x2 sums on the fp32 accumulators + the BatchNorm-backward sums of the layer
+    that produced x — against float64 autograd on the same bf16-rounded operands; ragged maps; the sums against the
+    stored (rounded) gradient; run-to-run identical"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(377 + h + Cout)
+    B = 2
+    yraw = torch.randn((B, Cin, h, w_), generator=g)
+    yg, y64 = bf(yraw)
+    sc = 1 + 0.3 * torch.randn(Cin, generator=g)
+    sh = 0.2 * torch.randn(Cin, generator=g)
+    mu = 0.1 * torch.randn(Cin, generator=g)
+    istd = 1 + 0.2 * torch.rand(Cin, generator=g)
+    wt = (torch.randn((Cout, Cin, 3, 3), generator=g) * 0.08).to(BF)
+    x = torch.randn((B, Cin, h, w_), generator=g, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt.double(), padding=1)
+    dy = torch.randn(out.shape, generator=g)
+    dyg, dy64 = bf(dy)
+    out.backward(dy64)
+    wd = ops.pack_weights_bf16(wt.float().permute(2, 3, 1, 0).contiguous().to(DEV), dgrad=True)
+    args = (dyg, wd, Cin, yg, mu.to(DEV), istd.to(DEV), sc.to(DEV), sh.to(DEV))
+    gx, red = ops.conv2d_bf16_upsampled_dgrad(*args)
+    close_bf16(to_nchw(gx), x.grad)
+    gx2, red2 = ops.conv2d_bf16_upsampled_dgrad(*args)
+    assert torch.equal(gx, gx2) and torch.equal(red, red2)
+    # sums over the STORED gradient, mask from bf16(y * scale + shift) like dt_bn_bwd_reduce_bf16
+    act = (y64.float() * sc[None, :, None, None] + sh[None, :, None, None]).to(BF).float()
+    gm = torch.where(act > 0, to_nchw(gx), torch.zeros((), dtype=torch.float64))
+    xhat = (y64 - mu.double()[None, :, None, None]) * istd.double()[None, :, None, None]
+    tol = 1e-4 * float(gm.abs().sum(dim=(0, 2, 3)).max())
+    np.testing.assert_allclose(red[0].double().sum(0).cpu(), gm.sum(dim=(0, 2, 3)), rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(red[1].double().sum(0).cpu(), (gm * xhat).sum(dim=(0, 2, 3)), rtol=1e-4, atol=3 * tol)
+
+
 @pytest.mark.parametrize("k,p", [(3, 1), (1, 0)])
 def test_conv_bf16_stride2_data_gradient(k, p):
     ops = _ops()
