@@ -37,8 +37,8 @@ PEAK_HBM_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="tiles per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,7 +113,9 @@ def main():
             import copy
             from deadtrees_amd.network.unet import UNetHIP
             ia = copy.copy(args)
-            ia.size, ia.batch, ia.steps, ia.warmup, ia.graph = 256, 64, 5, 2, "auto"
+            # 6.3 ms batches: enough of them that the leg is timed at steady clocks (5 + 2 right after the idle gap of the
+            # model set-up read 8.8 k sub-tiles/s where `--mode infer` alone reads 10.1 k)
+            ia.size, ia.batch, ia.steps, ia.warmup, ia.graph = 256, 64, 40, 10, "auto"
             im = UNetHIP(in_channels=3, classes=2)
             im.reset_parameters(seed=0)
             leg = infer_bench(ia, im.to(dev), dev, world, rank, distributed, as_leg=True)
@@ -578,8 +580,9 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
                 return model.predict_classes(x, dtype="uint8", precision=args.precision, nhwc=True)
 
         ortho = np.random.default_rng(7 + rank).integers(0, 256, (4, 2048, 2048), dtype=np.uint8)
-        infer_tile(_U8(), ortho, subtile=S, batch_size=64, device=str(dev))          # warm-up
-        n_ortho = 3
+        for _ in range(3):                                                             # warm-up (clocks: the raster above
+            infer_tile(_U8(), ortho, subtile=S, batch_size=64, device=str(dev))          # took ~50 ms of host time to draw)
+        n_ortho = 8
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()

@@ -128,45 +128,49 @@ def test_data_parallel_step_equals_sum_of_replica_gradients():
     assert all(r[3] for r in res)
 
 
-def _nan_worker(rank, world, port, q, precision):
+def _nan_worker(rank, world, port, q, precisions):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from deadtrees_amd.data.synthetic import synth_batch
-        from deadtrees_amd.network.unet import UNetHIP
-        from deadtrees_amd.trainer import HipTrainer
-        dev = "cuda:0"
-        torch.cuda.set_device(0)
-        img, mask = synth_batch(2, 64, 64, 3, 2, seed=70 + rank)
-        img, mask = img.to(dev), mask.to(dev)
-        m = UNetHIP()
-        m.reset_parameters(seed=5)
-        m.to(dev)
-        tr = HipTrainer(m, distributed=True, precision=precision)
-        tr.broadcast_parameters(0)
-        tr.step(img, mask)                                   # a clean step first: Adam state exists, t = 1
-        p1 = m.flat_params.detach().clone()
-        m1, v1 = tr.opt.m.clone(), tr.opt.v.clone()
-        bad = img.clone()
-        if rank == 1:
-            bad[0, 0, 0, 0] = float("nan")                   # ONE rank sees a non-finite loss
-        tr.step(bad, mask)
-        local_skip = int(tr.last["skipped"])                 # the flag after the MAX all-reduce: global
-        same = torch.equal(m.flat_params.detach(), p1) and torch.equal(tr.opt.m, m1) and torch.equal(tr.opt.v, v1)
-        steps = tr.opt.steps_applied()
-        tr.step(img, mask)                                   # training goes on, replicas identical
-        ps = [torch.empty_like(p1) for _ in range(world)]
-        dist.all_gather(ps, m.flat_params.data)
-        q.put((rank, local_skip, bool(same), steps, bool(torch.equal(ps[0], ps[1])), tr.opt.steps_applied(),
-               bool(torch.isfinite(m.flat_params).all())))
+        for precision in precisions:      # both precisions in ONE pair of processes (a spawn costs ~10 s of imports)
+            _nan_case(rank, world, q, precision)
     finally:
         dist.destroy_process_group()
 
 
+def _nan_case(rank, world, q, precision):
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.trainer import HipTrainer
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    img, mask = synth_batch(2, 64, 64, 3, 2, seed=70 + rank)
+    img, mask = img.to(dev), mask.to(dev)
+    m = UNetHIP()
+    m.reset_parameters(seed=5)
+    m.to(dev)
+    tr = HipTrainer(m, distributed=True, precision=precision)
+    tr.broadcast_parameters(0)
+    tr.step(img, mask)                                   # a clean step first: Adam state exists, t = 1
+    p1 = m.flat_params.detach().clone()
+    m1, v1 = tr.opt.m.clone(), tr.opt.v.clone()
+    bad = img.clone()
+    if rank == 1:
+        bad[0, 0, 0, 0] = float("nan")                   # ONE rank sees a non-finite loss
+    tr.step(bad, mask)
+    local_skip = int(tr.last["skipped"])                 # the flag after the MAX all-reduce: global
+    same = torch.equal(m.flat_params.detach(), p1) and torch.equal(tr.opt.m, m1) and torch.equal(tr.opt.v, v1)
+    steps = tr.opt.steps_applied()
+    tr.step(img, mask)                                   # training goes on, replicas identical
+    ps = [torch.empty_like(p1) for _ in range(world)]
+    dist.all_gather(ps, m.flat_params.data)
+    q.put((precision, rank, local_skip, bool(same), steps, bool(torch.equal(ps[0], ps[1])), tr.opt.steps_applied(),
+           bool(torch.isfinite(m.flat_params).all())))
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_nonfinite_loss_on_one_rank_skips_the_step_on_all_ranks(precision):
+def test_nonfinite_loss_on_one_rank_skips_the_step_on_all_ranks():
     """The gradient buckets are summed over the replicas BEFORE the skip decision, so the decision must be global:
     with a NaN batch on rank 1 only, both ranks skip (parameters and Adam moments bit-identical to before, the step
     count does not advance — Lightning does not call optimizer.step when training_step returns None), and the next
@@ -174,16 +178,18 @@ def test_nonfinite_loss_on_one_rank_skips_the_step_on_all_ranks(precision):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, q, precision)) for r in range(2)]
+    precisions = ("fp32", "bf16")
+    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, q, precisions)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=500) for _ in procs]
+    res = [q.get(timeout=500) for _ in range(2 * len(precisions))]
     for p in procs:
         p.join(60)
-    for rank, skip, same, steps, synced, steps_after, finite in res:
-        assert skip == 1, f"rank {rank} did not skip"
-        assert same, f"rank {rank}: parameters / Adam state moved in the skipped step"
-        assert steps == 1 and steps_after == 2, (rank, steps, steps_after)
+    assert sorted((r[0], r[1]) for r in res) == [("bf16", 0), ("bf16", 1), ("fp32", 0), ("fp32", 1)]
+    for precision, rank, skip, same, steps, synced, steps_after, finite in res:
+        assert skip == 1, f"{precision} rank {rank} did not skip"
+        assert same, f"{precision} rank {rank}: parameters / Adam state moved in the skipped step"
+        assert steps == 1 and steps_after == 2, (precision, rank, steps, steps_after)
         assert synced and finite
 
 
