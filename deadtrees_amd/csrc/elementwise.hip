@@ -681,10 +681,71 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const f32x4* __restric
   }
 }
 
+// Even maps (every training / fine-tuning tile): one thread per 2 x 2 block of input pixels.  Rows 2 q, 2 q + 1 and
+// columns 2 p, 2 p + 1 lie in the four windows (q, p), (q, p + 1), (q + 1, p), (q + 1, p + 1) and in no other, so each
+// window's gradient and index quad is loaded ONCE per block instead of once per pixel — the per-pixel form above reads
+// 6 bytes from L2 for every byte it writes (measured: 302 us for a 537 MB output, the L2 rate, not HBM's).  The four
+// pixels add their windows in the per-pixel kernel's order (oy, then ox, ascending): bit-identical.
+__global__ __launch_bounds__(256) void maxpool_bwd_quad_kernel(const f32x4* __restrict__ dout,
+                                                               const uint32_t* __restrict__ amax, f32x4* __restrict__ dx,
+                                                               int acc, int B, int H, int W, int C4, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    int64_t r = i / C4;
+    const int p = (int)(r % Wo);
+    r /= Wo;
+    const int q = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const bool q1 = q + 1 < Ho, p1 = p + 1 < Wo;
+    const int64_t o00 = i, o01 = i + C4, o10 = i + (int64_t)Wo * C4, o11 = o10 + C4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 d00 = dout[o00], d01 = p1 ? dout[o01] : z, d10 = q1 ? dout[o10] : z, d11 = (q1 && p1) ? dout[o11] : z;
+    // an index no tap has (0xff) for windows outside the map
+    const uint32_t a00 = amax[o00], a01 = p1 ? amax[o01] : 0xffffffffu, a10 = q1 ? amax[o10] : 0xffffffffu,
+                   a11 = (q1 && p1) ? amax[o11] : 0xffffffffu;
+    f32x4 g00 = z, g01 = z, g10 = z, g11 = z;   // pixels (2q, 2p), (2q, 2p+1), (2q+1, 2p), (2q+1, 2p+1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t t00 = (a00 >> (8 * k)) & 0xffu, t01 = (a01 >> (8 * k)) & 0xffu, t10 = (a10 >> (8 * k)) & 0xffu,
+                     t11 = (a11 >> (8 * k)) & 0xffu;
+      if (t00 == 4u) g00[k] += d00[k];
+      if (t00 == 5u) g01[k] += d00[k];
+      if (t01 == 3u) g01[k] += d01[k];
+      if (t00 == 7u) g10[k] += d00[k];
+      if (t10 == 1u) g10[k] += d10[k];
+      if (t00 == 8u) g11[k] += d00[k];
+      if (t01 == 6u) g11[k] += d01[k];
+      if (t10 == 2u) g11[k] += d10[k];
+      if (t11 == 0u) g11[k] += d11[k];
+    }
+    const int64_t x00 = (((int64_t)b * H + 2 * q) * W + 2 * p) * C4 + c4, x10 = x00 + (int64_t)W * C4;
+    if (acc) {
+      dx[x00] = dx[x00] + g00;
+      dx[x00 + C4] = dx[x00 + C4] + g01;
+      dx[x10] = dx[x10] + g10;
+      dx[x10 + C4] = dx[x10 + C4] + g11;
+    } else {
+      dx[x00] = g00;
+      dx[x00 + C4] = g01;
+      dx[x10] = g10;
+      dx[x10 + C4] = g11;
+    }
+  }
+}
+
 extern "C" int dt_maxpool3x3s2_bwd(const float* dout, const uint8_t* argmax, float* dx, int accumulate, int B,
                                    int H, int W, int C, void* stream) {
   DT_REQUIRE(dout && argmax && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "maxpool_bwd: bad args");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (((H | W) & 1) == 0) {
+    hipLaunchKernelGGL(maxpool_bwd_quad_kernel, dim3(ew_grid((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, (const f32x4*)dout, (const uint32_t*)argmax, (f32x4*)dx, accumulate, B, H, W,
+                       C / 4, Ho, Wo);
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
   const int64_t total = (int64_t)B * H * W * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                      (const f32x4*)dout, (const uint32_t*)argmax, (f32x4*)dx, accumulate, B, H, W, C / 4, Ho, Wo);

@@ -363,10 +363,80 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_kernel(const bf16x8* __r
   }
 }
 
+// even maps: one thread per 2 x 2 block of input pixels — each of the (at most four) windows it lies in is loaded once
+// (bf16 twin of maxpool_bwd_quad_kernel, elementwise.hip; same per-pixel summation order: bit-identical)
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_quad_kernel(const bf16x8* __restrict__ dout,
+                                                                    const uint2* __restrict__ amax, bf16x8* __restrict__ dx,
+                                                                    int acc, int B, int H, int W, int C8, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c8 = (int)(i % C8);
+    int64_t rr = i / C8;
+    const int p = (int)(rr % Wo);
+    rr /= Wo;
+    const int q = (int)(rr % Ho);
+    const int b = (int)(rr / Ho);
+    const bool q1 = q + 1 < Ho, p1 = p + 1 < Wo;
+    const int64_t o00 = i, o01 = i + C8, o10 = i + (int64_t)Wo * C8, o11 = o10 + C8;
+    float d00[8], d01[8], d10[8], d11[8];
+    const uint2 none = make_uint2(0xffffffffu, 0xffffffffu);    // an index no tap has
+    load8(dout, o00, d00);
+    load8(dout, p1 ? o01 : o00, d01);
+    load8(dout, q1 ? o10 : o00, d10);
+    load8(dout, (q1 && p1) ? o11 : o00, d11);
+    const uint2 a00 = amax[o00], a01 = p1 ? amax[o01] : none, a10 = q1 ? amax[o10] : none,
+                a11 = (q1 && p1) ? amax[o11] : none;
+    float g00[8], g01[8], g10[8], g11[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int sh = 8 * (k & 3);
+      const unsigned t00 = ((k < 4 ? a00.x : a00.y) >> sh) & 0xffu, t01 = ((k < 4 ? a01.x : a01.y) >> sh) & 0xffu,
+                     t10 = ((k < 4 ? a10.x : a10.y) >> sh) & 0xffu, t11 = ((k < 4 ? a11.x : a11.y) >> sh) & 0xffu;
+      float u00 = 0.f, u01 = 0.f, u10 = 0.f, u11 = 0.f;
+      if (t00 == 4u) u00 += d00[k];
+      if (t00 == 5u) u01 += d00[k];
+      if (t01 == 3u) u01 += d01[k];
+      if (t00 == 7u) u10 += d00[k];
+      if (t10 == 1u) u10 += d10[k];
+      if (t00 == 8u) u11 += d00[k];
+      if (t01 == 6u) u11 += d01[k];
+      if (t10 == 2u) u11 += d10[k];
+      if (t11 == 0u) u11 += d11[k];
+      g00[k] = u00; g01[k] = u01; g10[k] = u10; g11[k] = u11;
+    }
+    const int64_t x00 = (((int64_t)b * H + 2 * q) * W + 2 * p) * C8 + c8, x10 = x00 + (int64_t)W * C8;
+    const int64_t xs[4] = {x00, x00 + C8, x10, x10 + C8};
+    const float* gs[4] = {g00, g01, g10, g11};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bf16x8 o;
+      if (acc) {
+        float prev[8];
+        load8(dx, xs[e], prev);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)(prev[k] + gs[e][k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (__bf16)gs[e][k];
+      }
+      dx[xs[e]] = o;
+    }
+  }
+}
+
 extern "C" int dt_maxpool3x3s2_bwd_bf16(const void* dout, const uint8_t* argmax, void* dx, int accumulate, int B, int H,
                                         int W, int C, void* stream) {
   DT_REQUIRE(dout && argmax && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "maxpool_bwd_bf16: bad args");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (((H | W) & 1) == 0) {
+    int64_t gq = ((int64_t)B * Ho * Wo * (C / 8) + 255) / 256;
+    if (gq > 8192) gq = 8192;
+    hipLaunchKernelGGL(maxpool_bwd_bf16_quad_kernel, dim3((unsigned)gq), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16x8*)dout, (const uint2*)argmax, (bf16x8*)dx, accumulate, B, H, W, C / 8, Ho, Wo);
+    DT_LAUNCH_CHECK();
+    return DT_OK;
+  }
   const int64_t total = (int64_t)B * H * W * (C / 8);
   int64_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;

@@ -383,10 +383,11 @@ def test_bn_act_bf16(C):
     close_bf16(got32.cpu().double(), y.double() * sc.double() + sh.double())
 
 
-def test_maxpool_and_upsample_backward_bf16():
+@pytest.mark.parametrize("H,W", [(26, 30), (25, 31)])
+def test_maxpool_and_upsample_backward_bf16(H, W):
     ops = _ops()
     g = torch.Generator().manual_seed(5)
-    x = torch.randn((2, 16, 26, 30), generator=g)                  # NCHW reference layout
+    x = torch.randn((2, 16, H, W), generator=g)                    # NCHW reference layout
     xg = x.to(BF).permute(0, 2, 3, 1).contiguous().to(DEV)
     x64 = x.to(BF).double().requires_grad_(True)
     want = F.max_pool2d(x64, 3, 2, 1)
@@ -394,10 +395,10 @@ def test_maxpool_and_upsample_backward_bf16():
     assert torch.equal(pooled.cpu().permute(0, 3, 1, 2).double(), want.detach())
     d = torch.randn(want.shape, generator=g).to(BF)
     want.backward(d.double())
-    dx = ops.maxpool3x3s2_bwd_bf16(d.permute(0, 2, 3, 1).contiguous().to(DEV), am, 26, 30)
+    dx = ops.maxpool3x3s2_bwd_bf16(d.permute(0, 2, 3, 1).contiguous().to(DEV), am, H, W)
     close_bf16(dx.cpu().permute(0, 3, 1, 2).double(), x64.grad)
     prev = torch.randn(x.shape, generator=g).to(BF)
-    dx2 = ops.maxpool3x3s2_bwd_bf16(d.permute(0, 2, 3, 1).contiguous().to(DEV), am, 26, 30,
+    dx2 = ops.maxpool3x3s2_bwd_bf16(d.permute(0, 2, 3, 1).contiguous().to(DEV), am, H, W,
                                     dx=prev.permute(0, 2, 3, 1).contiguous().to(DEV))
     close_bf16(dx2.cpu().permute(0, 3, 1, 2).double(), x64.grad + prev.double())
     up = torch.randn((2, 24, 20, 32), generator=g).to(BF)          # NHWC

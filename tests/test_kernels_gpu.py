@@ -366,10 +366,12 @@ def test_batchnorm_train_forward_backward(C, shape):
     assert rel_err(to_nchw(dres), dout * (out.detach() > 0)) < 1e-6
 
 
-def test_maxpool_forward_backward_with_ties():
+@pytest.mark.parametrize("H,W", [(20, 28), (21, 27), (2, 2), (64, 6)])
+def test_maxpool_forward_backward_with_ties(H, W):
+    """even maps: one thread per 2 x 2 block of input pixels (maxpool_bwd_quad_kernel); odd maps: the per-pixel kernel"""
     ops = _ops()
     g = torch.Generator().manual_seed(3)
-    B, C, H, W = 2, 64, 20, 28
+    B, C = 2, 64
     x = F.relu(torch.randn((B, C, H, W), generator=g)).double()   # many exact zeros -> ties
     x.requires_grad_(True)
     out = F.max_pool2d(x, 3, 2, 1)
