@@ -78,6 +78,8 @@ SIGNATURES = {
     "dt_bn_eval_stats": (C.c_int, [c_f, c_f, F32, C.c_int, c_f, c_f, c_f]),
     "dt_channel_sums_workspace": (I64, [I64, C.c_int]),
     "dt_channel_sums": (C.c_int, [c_f, c_f, I64, C.c_int, c_f, c_f]),
+    "dt_channel_sums_bf16_workspace": (C.c_int64, [C.c_int64, C.c_int]),
+    "dt_channel_sums_bf16": (C.c_int, [c_f, c_f, C.c_int64, C.c_int, c_f, c_f]),
     "dt_channel_slice": (C.c_int, [c_f, c_f, I64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_maxpool3x3s2": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_maxpool3x3s2_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

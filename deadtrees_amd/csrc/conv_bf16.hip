@@ -828,12 +828,13 @@ __global__ __launch_bounds__(256) void bn_act_bf16_kernel(const void* __restrict
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float f = v[k] * sc[k] + sf[k];
+      if (relu == 2) f = f < 0.f ? 0.f : f;      // ReLU on the main branch only (ResUnet decoder: relu(bn2(.)) + identity_conv)
       if (res) {
         float rr = (float)rv[k];
         if (rscale) rr = rr * rsc[k] + rsf[k];
         f += rr;
       }
-      if (relu) f = f < 0.f ? 0.f : f;
+      if (relu == 1) f = f < 0.f ? 0.f : f;
       o[k] = (__bf16)f;
     }
     reinterpret_cast<bf16x8*>(out)[i] = o;
@@ -1169,7 +1170,7 @@ static int wb_validate(const dt_conv_desc* d) {
                "wgrad_bf16: ksize 4 is the space-to-depth stem only");
     return DT_OK;
   }
-  DT_REQUIRE((d->ksize == 3 && (d->stride == 1 || d->stride == 2)) || (d->ksize == 1 && d->stride == 2),
+  DT_REQUIRE((d->ksize == 3 || d->ksize == 1) && (d->stride == 1 || d->stride == 2),
              "wgrad_bf16: ksize/stride (%d,%d) unsupported", d->ksize, d->stride);
   DT_REQUIRE((d->C0 & 7) == 0 && (d->C1 & 7) == 0 && (d->Cout & 7) == 0, "wgrad_bf16: channels must be multiples of 8");
   DT_REQUIRE(d->mode0 >= 0 && d->mode0 <= 1, "wgrad_bf16: mode0");
@@ -1293,7 +1294,8 @@ extern "C" int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, con
     rc = DT_OK;
   } else if (d->ksize == 3 && d->stride == 1) rc = tw == 32 ? wb_launch<3, 1, 32>(a, grid, st) : wb_launch<3, 1, 16>(a, grid, st);
   else if (d->ksize == 3) rc = tw == 32 ? wb_launch<3, 2, 32>(a, grid, st) : wb_launch<3, 2, 16>(a, grid, st);
-  else rc = tw == 32 ? wb_launch<1, 2, 32>(a, grid, st) : wb_launch<1, 2, 16>(a, grid, st);
+  else if (d->stride == 2) rc = tw == 32 ? wb_launch<1, 2, 32>(a, grid, st) : wb_launch<1, 2, 16>(a, grid, st);
+  else rc = tw == 32 ? wb_launch<1, 1, 32>(a, grid, st) : wb_launch<1, 1, 16>(a, grid, st);   // ResUnet identity_conv
   if (rc != DT_OK) return rc;
   DT_REQUIRE((E & 3) == 0, "wgrad_bf16: weight tensor size must be a multiple of 4");
   const int64_t g = (E / 4 + 15) / 16;

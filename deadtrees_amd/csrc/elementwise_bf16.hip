@@ -446,6 +446,58 @@ extern "C" int dt_maxpool3x3s2_bwd_bf16(const void* dout, const uint8_t* argmax,
   return DT_OK;
 }
 
+// ------------------------------------------------------------------ per-channel sums of a bf16 gradient
+// bias gradient of a convolution without BatchNorm (the 1x1 identity_conv of the ResUnet decoder under AMP): bf16 twin of
+// dt_channel_sums (elementwise.hip) — row blocks -> fp32 partial rows -> fixed-order fp64 final, no atomics
+#define CSB_RB 256
+__global__ __launch_bounds__(256) void channel_sums_bf16_kernel(const bf16x8* __restrict__ g, float* __restrict__ part,
+                                                                int64_t n_pix, int C8) {
+  const int q = threadIdx.x % C8, rl = threadIdx.x / C8, RL = 256 / C8;
+  const int64_t p0 = (int64_t)blockIdx.x * CSB_RB;
+  int64_t p1 = p0 + CSB_RB;
+  if (p1 > n_pix) p1 = n_pix;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t p = p0 + rl; p < p1; p += RL) {
+    float v[8];
+    load8(g, p * C8 + q, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] += v[k];
+  }
+  __shared__ float sh[8][256];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sh[k][threadIdx.x] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 8 * C8) {
+    const int c = threadIdx.x, qq = c >> 3, k = c & 7;
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += sh[k][r * C8 + qq];   // fixed order
+    part[(size_t)blockIdx.x * (8 * C8) + c] = t;
+  }
+}
+
+__global__ void channel_sums_bf16_final_kernel(const float* __restrict__ part, int P, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)part[(size_t)p * C + c];
+    out[c] = (float)s;
+  }
+}
+
+extern "C" int64_t dt_channel_sums_bf16_workspace(int64_t n_pix, int C) { return (int64_t)dt_cdiv(n_pix, CSB_RB) * C; }
+
+extern "C" int dt_channel_sums_bf16(const void* g, float* workspace, int64_t n_pix, int C, float* out, void* stream) {
+  DT_REQUIRE(g && workspace && out && n_pix > 0 && C > 0, "channel_sums_bf16: bad args");
+  DT_REQUIRE((C & 7) == 0 && C <= 256 && 256 % (C / 8) == 0, "channel_sums_bf16: C/8 must divide 256, C <= 256 (C=%d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int P = dt_cdiv(n_pix, CSB_RB);
+  hipLaunchKernelGGL(channel_sums_bf16_kernel, dim3(P), dim3(256), 0, st, (const bf16x8*)g, workspace, n_pix, C / 8);
+  DT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(channel_sums_bf16_final_kernel, dim3(dt_cdiv(C, 64)), dim3(64), 0, st, workspace, P, C, out);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 // ------------------------------------------------------------------ nearest x2 upsample backward
 __global__ __launch_bounds__(256) void upsample2x_bwd_bf16_kernel(const bf16x8* __restrict__ dup, bf16x8* __restrict__ dx,
                                                                   int B, int H, int W, int C8) {

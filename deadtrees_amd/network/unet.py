@@ -646,6 +646,21 @@ class UNetEngine:
         self._stem_s2d = None
         return P, sbuf
 
+    def _resunet_join_bf16(self, blk, params, wb, d, skip, y2, ss2, B, H, W):
+        """ResUnet decoder block output under AMP: bf16(relu(y2 * scale2 + shift2) + identity_conv(up(d) | skip) + bias) —
+        the 1x1 identity convolution over the virtual (up-sampled, concatenated) input on the bf16 kernels, the join in
+        dt_bn_act_bf16 (relu = 2: ReLU on the main branch only)"""
+        ic, dev, bf = blk.idc, y2.device, torch.bfloat16
+        C0, C1 = d.shape[-1], (0 if skip is None else skip.shape[-1])
+        idesc = self._desc(B, H, W, C0, C1, 1, H, W, ic.cout, 1, 1, 0)
+        idy = torch.empty((B, H, W, ic.cout), dtype=bf, device=dev)
+        self._conv_bf16(idesc, d, skip, wb[ic.w_off:ic.w_off + ic.w_size], idy, None, None, None, "dt_conv2d_bf16(identity_conv)")
+        out = torch.empty((B, H, W, ic.cout), dtype=bf, device=dev)
+        _lib.check(self.lib.dt_bn_act_bf16(_p(y2), 0, _p(ss2[0]), _p(ss2[1]), _p(idy), _p(self._const_vec(1.0, ic.cout, dev)),
+                                           _p(params[ic.b_off:ic.b_off + ic.cout]), _p(out), B * H * W, ic.cout, 2, _stream()),
+                   "dt_bn_act_bf16")
+        return out
+
     def _bf16_weights(self, params: torch.Tensor, dgrad: bool = False, chunked: bool = False):
         """bf16 images of every conv weight except stem and head: [tap][Cout][Cin] for the forward convs, or the
         data-gradient image (HWIO with reversed taps).  Repacked when the flat parameter buffer changed: torch's
@@ -771,8 +786,8 @@ class UNetEngine:
                           want_argmax: Optional[str] = None):
         """eval-mode forward with bf16 activations/weights and fp32 accumulation (stem and head stay fp32)."""
         sp, lib = self.spec, self.lib
-        if sp.decoder_kind != "unet":
-            raise NotImplementedError("the bf16 path is built for the unet decoder only")
+        if sp.decoder_kind not in ("unet", "resunet"):
+            raise NotImplementedError("the bf16 path is built for the unet and resunet decoders (unet++: fp32 only)")
         if x_nchw.dim() != 4 or x_nchw.shape[1] != sp.in_channels:
             raise RuntimeError(f"expected input [B,{sp.in_channels},H,W], got {tuple(x_nchw.shape)}")
         B, Cin, H, W = x_nchw.shape
@@ -847,6 +862,10 @@ class UNetEngine:
         for i, blk in enumerate(sp.decoder):
             y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw, in_ss=d_ss)
             y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+            if sp.decoder_kind == "resunet":     # relu(bn2(conv2(.))) + identity_conv(up + skip) (resunet/decoder.py:40-52)
+                d, d_ss = self._resunet_join_bf16(blk, params, wb, d, skips[i], y2, ss2, B, h2, w2), None
+                dh, dw = h2, w2
+                continue
             if i == len(sp.decoder) - 1:
                 d, d_ss = bn_act(y2, ss2), None
             else:
@@ -867,8 +886,8 @@ class UNetEngine:
         """training-mode forward with bf16 activations / weights, fp32 accumulation, fp32 BatchNorm statistics
         (taken from the accumulators), fp32 master parameters.  Stem and head run in fp32."""
         sp, lib = self.spec, self.lib
-        if sp.decoder_kind != "unet":
-            raise NotImplementedError("the bf16 path is built for the unet decoder only")
+        if sp.decoder_kind not in ("unet", "resunet"):
+            raise NotImplementedError("the bf16 path is built for the unet and resunet decoders (unet++: fp32 only)")
         B, Cin, H, W = x_nchw.shape
         if H % 32 or W % 32 or Cin != sp.in_channels:
             raise RuntimeError(f"bad input {tuple(x_nchw.shape)}")
@@ -954,6 +973,17 @@ class UNetEngine:
         d, dh, dw, d_ss = feats[4], ch, cw, None
         skips = [feats[3], feats[2], feats[1], feats[0], None]
         for i, blk in enumerate(sp.decoder):
+            if sp.decoder_kind == "resunet":
+                # reference network/extra/resunet/decoder.py:40-52 under AMP: conv1 -> conv2 (conv-BN-ReLU each, both
+                # activations virtual) + the 1x1 identity_conv (bias) of the up-sampled + concatenated input; no activation
+                # after the sum; the block output is a stored bf16 tensor
+                y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw)
+                y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+                out = self._resunet_join_bf16(blk, params, wb, d, skips[i], y2, ss2, B, h2, w2)
+                self._tr(f"D{i}.out", out)
+                sv.d[f"D{i}"] = dict(x=d, skip=skips[i], y1=y1, y2=y2, H=h1, W=w1)
+                d, dh, dw, d_ss = out, h2, w2, None
+                continue
             y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw, in_ss=d_ss)
             # round 3: the activations of the 64+-channel decoder blocks are stored (bn_act, 4 B per element moved) so that
             # conv2 / the next conv1 AND their weight gradients run the pure LDS-DMA kernels (a DMA cannot transform);
@@ -1090,7 +1120,62 @@ class UNetEngine:
 
         skip_grads = [None] * 5
         g_red = None
-        for i in range(4, -1, -1):
+        if sp.decoder_kind == "resunet" and hd.sd_k == 1:
+            # the 1x1 head lives in the centre tap of the 3x3 head kernel: the other taps stay zero (like backward())
+            gw = grads[hd.w_off:hd.w_off + hd.w_size].view(K, 9, hd.cin)
+            gw[:, :4].zero_()
+            gw[:, 5:].zero_()
+        for i in (range(4, -1, -1) if sp.decoder_kind == "resunet" else ()):
+            # reverse of one ResUnet block (fp32 twin: _backward_resunet_block): g = gradient of the block output
+            blk, d = sp.decoder[i], S[f"D{i}"]
+            Hh, Ww = d["H"], d["W"]
+            ic, cx = blk.idc, blk.in_ch
+            sk = 0 if d["skip"] is None else d["skip"].shape[-1]
+            n_pix = B * Hh * Ww
+            wgrad(ic, d["x"], d["skip"], 1, Hh, Ww, g)                   # identity branch: dW over the virtual input
+            cws = self._buf("chsum_ws", int(lib.dt_channel_sums_bf16_workspace(n_pix, ic.cout)), device=dev)
+            _lib.check(lib.dt_channel_sums_bf16(_p(g), _p(cws), n_pix, ic.cout, _p(grads[ic.b_off:ic.b_off + ic.cout]), st),
+                       "dt_channel_sums_bf16")                            # its bias gradient = sum g
+            dy2 = bn_bwd(blk.conv2, g, None, d["y2"], virtual_act=True)   # main branch: both activations virtual
+            self._tr(f"D{i}.dy2", dy2)
+            wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+            dz1 = torch.empty(d["y1"].shape, dtype=bf, device=dev)
+            red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, d["y1"])
+            del dy2
+            self._tr(f"D{i}.dz1", dz1)
+            dy1 = bn_bwd(blk.conv1, dz1, None, d["y1"], virtual_act=True, reduced=red1)
+            self._tr(f"D{i}.dy1", dy1)
+            del dz1
+            wgrad(blk.conv1, d["x"], d["skip"], 1, Hh, Ww, dy1)
+            dup = torch.empty((B, Hh, Ww, cx), dtype=bf, device=dev)
+            dup_id = torch.empty((B, Hh, Ww, cx), dtype=bf, device=dev)
+            one = self._const_vec(1.0, max(cx, sk, 8), dev)
+            zero = self._const_vec(0.0, max(cx, sk, 8), dev)
+            if sk:
+                dskip = torch.empty(d["skip"].shape, dtype=bf, device=dev)
+                dskip_id = torch.empty(d["skip"].shape, dtype=bf, device=dev)
+                dgrad(blk.conv1, dy1, Hh, Ww, dup, dskip, split=cx)
+                dgrad(ic, g, Hh, Ww, dup_id, dskip_id, split=cx)
+                # gradient of the skip feature = the two branches' parts, one rounding
+                _lib.check(lib.dt_bn_act_bf16(_p(dskip), 0, _p(one), _p(zero), _p(dskip_id), None, None, _p(dskip), n_pix, sk,
+                                              0, st), "dt_bn_act_bf16")
+                skip_grads[3 - i] = dskip
+                self._tr(f"D{i}.dskip", dskip)
+                del dskip_id
+            else:
+                dgrad(blk.conv1, dy1, Hh, Ww, dup)
+                dgrad(ic, g, Hh, Ww, dup_id)
+            del dy1
+            _lib.check(lib.dt_bn_act_bf16(_p(dup), 0, _p(one), _p(zero), _p(dup_id), None, None, _p(dup), n_pix, cx, 0, st),
+                       "dt_bn_act_bf16")
+            del dup_id
+            self._tr(f"D{i}.dup", dup)
+            g = torch.empty(d["x"].shape, dtype=bf, device=dev)
+            _lib.check(lib.dt_upsample2x_bwd_bf16(_p(dup), _p(g), B, Hh // 2, Ww // 2, cx, st), "dt_upsample2x_bwd_bf16")
+            del dup
+            self._tr(f"D{i}.g", g)
+            S[f"D{i}"] = None
+        for i in (range(4, -1, -1) if sp.decoder_kind == "unet" else ()):
             blk, d = sp.decoder[i], S[f"D{i}"]
             Hh, Ww = d["H"], d["W"]
             # the ReLU mask is recomputed from y2 * scale + shift even where z2 was stored (same arithmetic as bn_act:

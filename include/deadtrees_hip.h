@@ -183,6 +183,9 @@ int dt_channel_slice(const float* src, float* dst, int64_t n_pix, int C_narrow, 
  * third output; here the 1x1 identity_conv of the ResUnet decoder).  workspace: dt_channel_sums_workspace floats. */
 int64_t dt_channel_sums_workspace(int64_t n_pix, int C);
 int dt_channel_sums(const float* g, float* workspace, int64_t n_pix, int C, float* out, void* stream);
+/* bf16 twin (g bf16, fp32 sums; C a multiple of 8, at most 256): the identity_conv bias gradient under AMP */
+int64_t dt_channel_sums_bf16_workspace(int64_t n_pix, int C);
+int dt_channel_sums_bf16(const void* g_bf16, float* workspace, int64_t n_pix, int C, float* out, void* stream);
 
 /* ------------------------------------------------------------------ pooling / resampling (K4,K9 bwd) */
 /* max_pool2d(k=3,s=2,p=1) NHWC; argmax (uint8 window position, first max in scan order like ATen). */
@@ -343,7 +346,8 @@ size_t dt_conv2d_wgrad_bf16_workspace(const dt_conv_desc* d);
 int dt_conv2d_wgrad_bf16(const dt_conv_desc* d, const void* src0, const void* src1, const void* dy, float* dw_hwio,
                          float* workspace, size_t workspace_bytes, const float* in_scale, const float* in_shift,
                          void* stream);
-/* out(bf16) = act(y*scale+shift + res'), y fp32 (y_is_f32) or bf16, res bf16 (optional affine) */
+/* out(bf16) = act(y*scale+shift + res'), y fp32 (y_is_f32) or bf16, res bf16 (optional affine); relu: 0 none, 1 ReLU after
+ * the sum, 2 ReLU on the main branch only — relu(y*scale+shift) + res' (ResUnet decoder block, like dt_bn_act) */
 int dt_bn_act_bf16(const void* y, int y_is_f32, const float* scale, const float* shift, const void* res,
                    const float* rscale, const float* rshift, void* out, int64_t n_pix, int C, int relu, void* stream);
 int dt_maxpool3x3s2_bf16(const void* x, void* out, int B, int H, int W, int C, void* stream);

@@ -26,6 +26,9 @@ backward
   * nearest-upsample backward: (a+b)+(c+d) of bf16 values, one rounding; max-pool backward joins likewise; the
     narrow decoder block without a skip (dec4, channels 16 / 32, maps >= 8 x 32) sums the UNROUNDED data-gradient
     accumulators instead and rounds once (round 3: one kernel, dt_conv2d_bf16_upsampled_dgrad);
+  * ResUnet decoder (round 3, ``ResUNetR34Ref`` from resunet_ref.py): the 1x1 identity_conv output stored as bf16
+    without its bias, block output bf16(relu(y2*s2+b2) + (idy + bias)); backward: the two branches' data gradients
+    stored as bf16, added in fp32, one rounding, then the 2x2 sums; identity_conv dW / db in wide precision;
   * weight gradients: bf16 operands (the staged, rounded activation), wide accumulation, fp32 result.
 
 Two ways to use it (tests/test_bf16_gpu.py):
@@ -179,12 +182,23 @@ class Bf16TrainOracle:
             y1, ss1 = self._conv_bn(blk.conv1[0], blk.conv1[1], xin, f"{n}.y1")
             z1 = self._virt(y1, ss1)
             y2, ss2 = self._conv_bn(blk.conv2[0], blk.conv2[1], z1, f"{n}.y2")
+            if hasattr(blk, "identity_conv"):
+                # ResUnet block (reference extra/resunet/decoder.py:40-52) as the HIP path rounds it: the 1x1 identity
+                # convolution of the (up-sampled, concatenated) input is stored as bf16 WITHOUT its bias; the join is
+                # bf16(relu(y2 * scale + shift) + (idy * 1 + bias)) in fp32 (dt_bn_act_bf16, relu = 2)
+                idc = blk.identity_conv
+                idy = rbf(F.conv2d(xin.to(dt), self._w(idc))).float()
+                f = F.relu(_aff32(y2, ss2[0], ss2[1])) + (idy * 1.0 + idc.bias.detach().float()[None, :, None, None])
+                out = self._t(f"{n}.out", rbf(f).to(dt))
+                S[n] = dict(xin=xin, cx=xa.shape[1], y1=y1, ss1=ss1, y2=y2, ss2=ss2, z2=None)
+                d, d_ss = out, None
+                continue
             last = i == len(dec.blocks) - 1
             z2 = self._t(f"{n}.z2", self._virt(y2, ss2)) if last else None
             S[n] = dict(xin=xin, cx=xa.shape[1], y1=y1, ss1=ss1, y2=y2, ss2=ss2, z2=z2)
             d, d_ss = (z2, None) if last else (y2, ss2)
         head = r.segmentation_head[0]
-        logits = F.conv2d(d.to(dt), head.weight.detach().to(dt), head.bias.detach().to(dt), padding=1)
+        logits = F.conv2d(d.to(dt), head.weight.detach().to(dt), head.bias.detach().to(dt), padding=head.padding)
         logits = self._t("logits", logits.float())
         S["head"] = dict(x=d)
         self.saved = S
@@ -222,6 +236,30 @@ class Bf16TrainOracle:
     def _dgrad(self, conv, in_shape, dy):
         return conv2d_input(in_shape, self._w(conv), dy.to(self.dt), stride=conv.stride, padding=conv.padding)
 
+    def _resunet_block_backward(self, blk, d, p, n, g, skip_grads, slot):
+        """reverse of one ResUnet decoder block with the HIP path's rounding points (backward_bf16): both branches' data
+        gradients are stored as bf16, added in fp32 and rounded once; then the 2x2 sums of the up-sampling"""
+        dt = self.dt
+        idc, xin, cx = blk.identity_conv, d["xin"], d["cx"]
+        self._wgrad(idc, f"{p}.identity_conv.weight", xin, g)
+        self.grads[f"{p}.identity_conv.bias"] = g.double().sum(dim=(0, 2, 3)).float()
+        dy2, _ = self._bn_bwd(blk.conv2[1], f"{p}.conv2.1", g, d["y2"], d["ss2"], virtual=True)
+        dy2 = self._t(f"{n}.dy2", dy2)
+        z1 = self._virt(d["y1"], d["ss1"])
+        self._wgrad(blk.conv2[0], f"{p}.conv2.0.weight", z1, dy2)
+        dz1 = self._t(f"{n}.dz1", rbf(self._dgrad(blk.conv2[0], z1.shape, dy2)).to(dt))
+        dy1, _ = self._bn_bwd(blk.conv1[1], f"{p}.conv1.1", dz1, d["y1"], d["ss1"], virtual=True)
+        dy1 = self._t(f"{n}.dy1", dy1)
+        self._wgrad(blk.conv1[0], f"{p}.conv1.0.weight", xin, dy1)
+        da = rbf(self._dgrad(blk.conv1[0], xin.shape, dy1)).float()
+        db = rbf(self._dgrad(idc, xin.shape, g)).float()
+        if xin.shape[1] > cx:
+            skip_grads[slot] = self._t(f"{n}.dskip", rbf(da[:, cx:] + db[:, cx:]).to(dt))
+        dup = self._t(f"{n}.dup", rbf(da[:, :cx] + db[:, :cx]).to(dt))
+        a, b_, c, e = (dup[:, :, 0::2, 0::2].float(), dup[:, :, 0::2, 1::2].float(), dup[:, :, 1::2, 0::2].float(),
+                       dup[:, :, 1::2, 1::2].float())
+        return self._t(f"{n}.g", rbf((a + b_) + (c + e)).to(dt))
+
     # ------------------------------------------------------------------ backward
     def backward(self, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
         r, dt, S = self.ref, self.dt, self.saved
@@ -230,14 +268,17 @@ class Bf16TrainOracle:
         head = r.segmentation_head[0]
         hx = S["head"]["x"]
         dl = dlogits.to(dt)
-        self.grads["segmentation_head.0.weight"] = conv2d_weight(hx.to(dt), head.weight.shape, dl, padding=1).float()
+        self.grads["segmentation_head.0.weight"] = conv2d_weight(hx.to(dt), head.weight.shape, dl, padding=head.padding).float()
         self.grads["segmentation_head.0.bias"] = dl.sum(dim=(0, 2, 3)).float()
-        g = self._t("head.g", rbf(conv2d_input(hx.shape, head.weight.detach().to(dt), dl, padding=1)).to(dt))
+        g = self._t("head.g", rbf(conv2d_input(hx.shape, head.weight.detach().to(dt), dl, padding=head.padding)).to(dt))
 
         skip_grads = [None] * 5
         for i in range(4, -1, -1):
             blk, d = dec.blocks[i], S[f"D{i}"]
             p, n = f"decoder.blocks.{i}", f"D{i}"
+            if hasattr(blk, "identity_conv"):
+                g = self._resunet_block_backward(blk, d, p, n, g, skip_grads, 3 - i)
+                continue
             dy2, _ = self._bn_bwd(blk.conv2[1], f"{p}.conv2.1", g, d["y2"], d["ss2"], mask_from=d["z2"],
                                   virtual=d["z2"] is None)
             dy2 = self._t(f"{n}.dy2", dy2)

@@ -120,5 +120,18 @@ def test_resunet_trains_through_semsegment_and_hiptrainer():
     hd = model.model.spec.head
     w = model.model.flat_params.detach()[hd.w_off:hd.w_off + hd.w_size].view(2, 9, 16)
     assert float(w[:, :4].abs().max()) == 0.0 and float(w[:, 5:].abs().max()) == 0.0      # off-centre taps stay zero
+    # under AMP (round 3: bf16 forms of the ResUnet decoder — teacher-forced parity in tests/test_bf16_e2e_gpu.py): the same
+    # model keeps training, with HIP-graph replay too; the 1x1 head stays 1x1; bf16 inference agrees with fp32 on the class maps
+    trb = HipTrainer(model.model, lr=3e-4, precision="bf16", graph=True)
+    lb = [float(trb.step(img.to(DEV), mask.to(DEV))) for _ in range(8)]
+    assert np.isfinite(lb).all() and lb[-1] < losses[0], lb
+    w = model.model.flat_params.detach()[hd.w_off:hd.w_off + hd.w_size].view(2, 9, 16)
+    assert float(w[:, :4].abs().max()) == 0.0 and float(w[:, 5:].abs().max()) == 0.0
+    model.model.eval()
+    a32 = model.model.predict_classes(img.to(DEV), dtype="uint8")
+    a16 = model.model.predict_classes(img.to(DEV), dtype="uint8", precision="bf16")
+    assert float((a32 == a16).float().mean()) > 0.97
+    # unet++ has no bf16 form: loud, not a silent fp32 fallback
+    pp = SemSegment(default_network(architecture="unet++"), default_training()).to(DEV)
     with pytest.raises(NotImplementedError):
-        HipTrainer(model.model, precision="bf16").step(img.to(DEV), mask.to(DEV))
+        HipTrainer(pp.model, precision="bf16").step(img.to(DEV), mask.to(DEV))
