@@ -146,6 +146,8 @@ SIGNATURES = {
     "dt_maxpool3x3s2_bf16_amax": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_maxpool3x3s2_bwd_bf16": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_upsample2x_bwd_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_upsample2x_bwd_acc_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_channel_slice_bf16": (C.c_int, [c_f, c_f, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_sumsq_rows": (C.c_int, [I64]),
     "dt_sumsq": (C.c_int, [c_f, I64, c_f, c_f]),
     "dt_clip_coef": (C.c_int, [c_f, C.c_int, F32, F32, c_f, c_f, c_f, c_f]),

@@ -500,7 +500,7 @@ extern "C" int dt_channel_sums_bf16(const void* g, float* workspace, int64_t n_p
 
 // ------------------------------------------------------------------ nearest x2 upsample backward
 __global__ __launch_bounds__(256) void upsample2x_bwd_bf16_kernel(const bf16x8* __restrict__ dup, bf16x8* __restrict__ dx,
-                                                                  int B, int H, int W, int C8) {
+                                                                  int acc, int B, int H, int W, int C8) {
   const int64_t total = (int64_t)B * H * W * C8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int W2 = 2 * W;
@@ -518,19 +518,74 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_bf16_kernel(const bf16x8* 
     load8(dup, base + (int64_t)W2 * C8, c);
     load8(dup, base + (int64_t)W2 * C8 + C8, d);
     bf16x8 o;
+    if (acc) {   // a node of a dense decoder collects the gradients of several consumers: one rounding per contribution
+      float prev[8];
+      load8(dx, i, prev);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (__bf16)((a[k] + bq[k]) + (c[k] + d[k]));
+      for (int k = 0; k < 8; ++k) o[k] = (__bf16)(prev[k] + ((a[k] + bq[k]) + (c[k] + d[k])));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (__bf16)((a[k] + bq[k]) + (c[k] + d[k]));
+    }
     dx[i] = o;
   }
 }
 
-extern "C" int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C, void* stream) {
+static int upsample2x_bwd_bf16_launch(const void* dup, void* dx, int acc, int B, int H, int W, int C, void* stream) {
   DT_REQUIRE(dup && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "upsample2x_bwd_bf16: bad args");
   const int64_t total = (int64_t)B * H * W * (C / 8);
   int64_t g = (total + 255) / 256;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(upsample2x_bwd_bf16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16x8*)dup, (bf16x8*)dx, B, H, W, C / 8);
+                     (const bf16x8*)dup, (bf16x8*)dx, acc, B, H, W, C / 8);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
+extern "C" int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C, void* stream) {
+  return upsample2x_bwd_bf16_launch(dup, dx, 0, B, H, W, C, stream);
+}
+
+// dx (+)= 2x2 sums: accumulate != 0 adds to the bf16 gradient already in dx (Unet++ nodes with several consumers)
+extern "C" int dt_upsample2x_bwd_acc_bf16(const void* dup, void* dx, int accumulate, int B, int H, int W, int C, void* stream) {
+  return upsample2x_bwd_bf16_launch(dup, dx, accumulate, B, H, W, C, stream);
+}
+
+// ------------------------------------------------------------------ channel-slice copies of bf16 tensors (Unet++ under AMP)
+// bf16 twin of dt_channel_slice: wide[n, off : off + Cn] = narrow[n, :]  /  narrow[n, :] (+)= wide[n, off : off + Cn];
+// channel counts and the offset multiples of 8 (16-byte units); the accumulating form adds in fp32 and rounds once
+__global__ __launch_bounds__(256) void channel_slice_bf16_kernel(const bf16x8* __restrict__ src, bf16x8* __restrict__ dst,
+                                                                 int64_t n8, int Cn8, int Cw8, int off8, int to_wide, int acc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const int64_t pix = i / Cn8;
+    const int c = (int)(i - pix * Cn8);
+    const int64_t w = pix * Cw8 + off8 + c;
+    if (to_wide) {
+      dst[w] = src[i];
+    } else if (!acc) {
+      dst[i] = src[w];
+    } else {
+      float a[8], b[8];
+      load8(src, w, a);
+      load8(dst, i, b);
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (__bf16)(b[k] + a[k]);
+      dst[i] = o;
+    }
+  }
+}
+
+extern "C" int dt_channel_slice_bf16(const void* src, void* dst, int64_t n_pix, int C_narrow, int C_wide, int offset,
+                                     int to_wide, int accumulate, void* stream) {
+  DT_REQUIRE(src && dst && n_pix > 0 && C_narrow > 0 && C_wide >= C_narrow, "channel_slice_bf16: bad args");
+  DT_REQUIRE((C_narrow & 7) == 0 && (C_wide & 7) == 0 && (offset & 7) == 0 && offset >= 0 && offset + C_narrow <= C_wide,
+             "channel_slice_bf16: channel counts and offset must be multiples of 8 inside the wide tensor");
+  const int64_t n8 = n_pix * (C_narrow / 8);
+  const int grid = (int)(n8 / 256 + 1 < 8192 ? n8 / 256 + 1 : 8192);
+  hipLaunchKernelGGL(channel_slice_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)src,
+                     (bf16x8*)dst, n8, C_narrow / 8, C_wide / 8, offset / 8, to_wide, accumulate);
   DT_LAUNCH_CHECK();
   return DT_OK;
 }

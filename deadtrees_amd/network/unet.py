@@ -567,11 +567,13 @@ class UNetEngine:
             return tensors[0], [(0, tensors[0].shape[-1])]
         B, H, W = tensors[0].shape[:3]
         Cw = sum(t.shape[-1] for t in tensors)
-        wide = torch.empty((B, H, W, Cw), dtype=torch.float32, device=tensors[0].device)
+        bf = tensors[0].dtype == torch.bfloat16
+        wide = torch.empty((B, H, W, Cw), dtype=tensors[0].dtype, device=tensors[0].device)
+        slice_fn = self.lib.dt_channel_slice_bf16 if bf else self.lib.dt_channel_slice
         parts, off = [], 0
         for t in tensors:
             Cn = t.shape[-1]
-            _lib.check(self.lib.dt_channel_slice(_p(t), _p(wide), B * H * W, Cn, Cw, off, 1, 0, _stream()), "dt_channel_slice")
+            _lib.check(slice_fn(_p(t), _p(wide), B * H * W, Cn, Cw, off, 1, 0, _stream()), "dt_channel_slice")
             parts.append((off, Cn))
             off += Cn
         return wide, parts
@@ -786,8 +788,6 @@ class UNetEngine:
                           want_argmax: Optional[str] = None):
         """eval-mode forward with bf16 activations/weights and fp32 accumulation (stem and head stay fp32)."""
         sp, lib = self.spec, self.lib
-        if sp.decoder_kind not in ("unet", "resunet"):
-            raise NotImplementedError("the bf16 path is built for the unet and resunet decoders (unet++: fp32 only)")
         if x_nchw.dim() != 4 or x_nchw.shape[1] != sp.in_channels:
             raise RuntimeError(f"expected input [B,{sp.in_channels},H,W], got {tuple(x_nchw.shape)}")
         B, Cin, H, W = x_nchw.shape
@@ -859,7 +859,17 @@ class UNetEngine:
             feats.append(cur)
         d, dh, dw, d_ss = feats[4], ch, cw, None
         skips = [feats[3], feats[2], feats[1], feats[0], None]
-        for i, blk in enumerate(sp.decoder):
+        if sp.decoder_kind == "unetplusplus":      # dense decoder (fp32 twin: _forward_unetpp): node outputs are stored tensors
+            nodes = {f"f{k}": feats[4 - k] for k in range(5)}
+            for blk in sp.decoder:
+                low = nodes[blk.low]
+                skip = None if not blk.cat else self._cat_channels([nodes[n] for n in blk.cat])[0]
+                y1, h1, w1, ss1 = conv(blk.conv1, low, skip, 1, 2 * low.shape[1], 2 * low.shape[2])
+                y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+                nodes[blk.name] = bn_act(y2, ss2)
+            d = nodes[sp.decoder[-1].name]
+            dh, dw = d.shape[1], d.shape[2]
+        for i, blk in enumerate(sp.decoder if sp.decoder_kind != "unetplusplus" else ()):
             y1, h1, w1, ss1 = conv(blk.conv1, d, skips[i], 1, 2 * dh, 2 * dw, in_ss=d_ss)
             y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
             if sp.decoder_kind == "resunet":     # relu(bn2(conv2(.))) + identity_conv(up + skip) (resunet/decoder.py:40-52)
@@ -886,8 +896,6 @@ class UNetEngine:
         """training-mode forward with bf16 activations / weights, fp32 accumulation, fp32 BatchNorm statistics
         (taken from the accumulators), fp32 master parameters.  Stem and head run in fp32."""
         sp, lib = self.spec, self.lib
-        if sp.decoder_kind not in ("unet", "resunet"):
-            raise NotImplementedError("the bf16 path is built for the unet and resunet decoders (unet++: fp32 only)")
         B, Cin, H, W = x_nchw.shape
         if H % 32 or W % 32 or Cin != sp.in_channels:
             raise RuntimeError(f"bad input {tuple(x_nchw.shape)}")
@@ -972,7 +980,22 @@ class UNetEngine:
             feats.append(cur)
         d, dh, dw, d_ss = feats[4], ch, cw, None
         skips = [feats[3], feats[2], feats[1], feats[0], None]
-        for i, blk in enumerate(sp.decoder):
+        if sp.decoder_kind == "unetplusplus":
+            # smp UnetPlusPlus under AMP (fp32 twin: _forward_unetpp): every node = DecoderBlock(up x2 of its lower node, cat of
+            # the nodes / encoder feature on its level); node outputs are stored bf16 activations (several consumers), conv2
+            # reads conv1's raw output with BatchNorm + ReLU applied while staging
+            nodes = {f"f{k}": feats[4 - k] for k in range(5)}
+            for blk in sp.decoder:
+                low = nodes[blk.low]
+                skip, parts = (None, []) if not blk.cat else self._cat_channels([nodes[n] for n in blk.cat])
+                y1, h1, w1, ss1 = conv(blk.conv1, low, skip, 1, 2 * low.shape[1], 2 * low.shape[2])
+                y2, h2, w2, ss2 = conv(blk.conv2, y1, None, 0, h1, w1, in_ss=ss1)
+                z2 = bn_act(y2, ss2)
+                sv.d["P" + blk.name] = dict(x=low, skip=skip, parts=parts, y1=y1, y2=y2, z2=z2, H=h1, W=w1)
+                nodes[blk.name] = z2
+            d = nodes[sp.decoder[-1].name]
+            dh, dw = d.shape[1], d.shape[2]
+        for i, blk in enumerate(sp.decoder if sp.decoder_kind != "unetplusplus" else ()):
             if sp.decoder_kind == "resunet":
                 # reference network/extra/resunet/decoder.py:40-52 under AMP: conv1 -> conv2 (conv-BN-ReLU each, both
                 # activations virtual) + the 1x1 identity_conv (bias) of the up-sampled + concatenated input; no activation
@@ -1125,6 +1148,66 @@ class UNetEngine:
             gw = grads[hd.w_off:hd.w_off + hd.w_size].view(K, 9, hd.cin)
             gw[:, :4].zero_()
             gw[:, 5:].zero_()
+        if sp.decoder_kind == "unetplusplus":
+            # reverse of the dense decoder (fp32 twin: _backward_unetpp): blocks in reverse forward order; a node's gradient is
+            # the sum over its consumers — as the up-sampled input of the block to its right (accumulating 2x2 sums) and as a
+            # slice of the concatenated skip of the blocks further right (accumulating slice copies), one rounding each
+            G = {sp.decoder[-1].name: g}
+
+            def slot(name, shape):
+                t = G.get(name)
+                if t is None:
+                    t = G[name] = torch.empty(shape, dtype=bf, device=dev)
+                    return t, 0
+                return t, 1
+
+            for blk in reversed(sp.decoder):
+                d = S["P" + blk.name]
+                g = G.pop(blk.name)
+                self._tr(f"P{blk.name}.g", g)
+                Hh, Ww = d["H"], d["W"]
+                dy2 = bn_bwd(blk.conv2, g, None, d["y2"], virtual_act=True)
+                self._tr(f"P{blk.name}.dy2", dy2)
+                del g
+                wgrad(blk.conv2, d["y1"], None, 0, Hh, Ww, dy2, in_ss=self._ss(blk.conv1, bnws))
+                dz1 = torch.empty(d["y1"].shape, dtype=bf, device=dev)
+                red1 = dgrad_bn(blk.conv2, dy2, Hh, Ww, dz1, blk.conv1, d["y1"])
+                del dy2
+                self._tr(f"P{blk.name}.dz1", dz1)
+                dy1 = bn_bwd(blk.conv1, dz1, None, d["y1"], virtual_act=True, reduced=red1)
+                self._tr(f"P{blk.name}.dy1", dy1)
+                del dz1
+                wgrad(blk.conv1, d["x"], d["skip"], 1, Hh, Ww, dy1)
+                cx = blk.in_ch
+                dup = torch.empty((B, Hh, Ww, cx), dtype=bf, device=dev)
+                dskip = None
+                if d["skip"] is not None:
+                    dskip = torch.empty(d["skip"].shape, dtype=bf, device=dev)
+                    dgrad(blk.conv1, dy1, Hh, Ww, dup, dskip, split=cx)
+                    self._tr(f"P{blk.name}.dskip", dskip)
+                else:
+                    dgrad(blk.conv1, dy1, Hh, Ww, dup)
+                self._tr(f"P{blk.name}.dup", dup)
+                del dy1
+                glow, acc = slot(blk.low, d["x"].shape)
+                _lib.check(lib.dt_upsample2x_bwd_acc_bf16(_p(dup), _p(glow), acc, B, Hh // 2, Ww // 2, cx, st),
+                           "dt_upsample2x_bwd_acc_bf16")
+                del dup
+                if dskip is not None:
+                    Cw = dskip.shape[-1]
+                    for name, (off, Cn) in zip(blk.cat, d["parts"]):
+                        if len(blk.cat) == 1 and name not in G:
+                            G[name] = dskip                      # the skip was the tensor itself: its gradient as is
+                            continue
+                        gm, acc = slot(name, (B, Hh, Ww, Cn))
+                        _lib.check(lib.dt_channel_slice_bf16(_p(dskip), _p(gm), B * Hh * Ww, Cn, Cw, off, 0, acc, st),
+                                   "dt_channel_slice_bf16")
+                S["P" + blk.name] = None
+            for k in range(1, 5):
+                skip_grads[4 - k] = G[f"f{k}"]      # f_k of the decoder = feats[4 - k]
+                self._tr(f"Pf{k}.g", G[f"f{k}"])
+            g = G["f0"]
+            self._tr("Pf0.g", g)
         for i in (range(4, -1, -1) if sp.decoder_kind == "resunet" else ()):
             # reverse of one ResUnet block (fp32 twin: _backward_resunet_block): g = gradient of the block output
             blk, d = sp.decoder[i], S[f"D{i}"]

@@ -380,6 +380,12 @@ int dt_maxpool3x3s2_bf16_amax(const void* x, void* out, uint8_t* argmax, int B, 
 int dt_maxpool3x3s2_bwd_bf16(const void* dout, const uint8_t* argmax, void* dx, int accumulate, int B, int H, int W,
                              int C, void* stream);
 int dt_upsample2x_bwd_bf16(const void* dup, void* dx, int B, int H, int W, int C, void* stream);
+/* the same with accumulate != 0: dx = bf16(dx + sums) — a node of the Unet++ dense decoder collects several consumers */
+int dt_upsample2x_bwd_acc_bf16(const void* dup, void* dx, int accumulate, int B, int H, int W, int C, void* stream);
+/* bf16 twin of dt_channel_slice (channel counts and offset multiples of 8): torch.cat of the dense skip connections of
+ * smp UnetPlusPlusDecoder.forward under AMP and its backward; the accumulating form adds in fp32 and rounds once */
+int dt_channel_slice_bf16(const void* src, void* dst, int64_t n_pix, int C_narrow, int C_wide, int offset, int to_wide,
+                          int accumulate, void* stream);
 
 /* Every weight image of a network in one launch, table-driven over the flat parameter buffer: table int32
  * [n_layers][5] = (w_off, taps, Cin, Cout, first_tile) on the DEVICE, first_tile = running sum of

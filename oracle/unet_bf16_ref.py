@@ -26,6 +26,9 @@ backward
   * nearest-upsample backward: (a+b)+(c+d) of bf16 values, one rounding; max-pool backward joins likewise; the
     narrow decoder block without a skip (dec4, channels 16 / 32, maps >= 8 x 32) sums the UNROUNDED data-gradient
     accumulators instead and rounds once (round 3: one kernel, dt_conv2d_bf16_upsampled_dgrad);
+  * Unet++ dense decoder (round 3, ``UNetPPR34Ref`` from unetpp_ref.py): node outputs stored as bf16 activations; in the
+    backward a node's gradient collects its consumers' contributions in reverse forward order, bf16(prev + contribution)
+    per step (2x2 sums of the block to its right, channel slices of the concatenated skips further right);
   * ResUnet decoder (round 3, ``ResUNetR34Ref`` from resunet_ref.py): the 1x1 identity_conv output stored as bf16
     without its bias, block output bf16(relu(y2*s2+b2) + (idy + bias)); backward: the two branches' data gradients
     stored as bf16, added in fp32, one rounding, then the 2x2 sums; identity_conv dW / db in wide precision;
@@ -173,7 +176,23 @@ class Bf16TrainOracle:
             feats.append(cur)
         d, d_ss = feats[4], None
         skips = [feats[3], feats[2], feats[1], feats[0], None]
-        for i, blk in enumerate(dec.blocks):
+        dense = isinstance(dec.blocks, torch.nn.ModuleDict)      # smp UnetPlusPlus (unetpp_ref.UNetPPR34Ref)
+        if dense:
+            nodes = {f"f{k}": feats[4 - k] for k in range(5)}
+            for name, low, cat in self._dense_order(dec):
+                blk, n = dec.blocks[name], "P" + name
+                xin = F.interpolate(nodes[low].to(dt), scale_factor=2, mode="nearest")
+                if cat:
+                    xin = torch.cat([xin] + [nodes[c].to(dt) for c in cat], dim=1)
+                y1, ss1 = self._conv_bn(blk.conv1[0], blk.conv1[1], xin, f"{n}.y1")
+                z1 = self._virt(y1, ss1)
+                y2, ss2 = self._conv_bn(blk.conv2[0], blk.conv2[1], z1, f"{n}.y2")
+                z2 = self._t(f"{n}.z2", self._virt(y2, ss2))      # node outputs are stored activations
+                S[n] = dict(xin=xin, cx=nodes[low].shape[1], y1=y1, ss1=ss1, y2=y2, ss2=ss2, z2=z2,
+                            widths=[nodes[c].shape[1] for c in cat])
+                nodes[name] = z2
+            d = nodes[f"x_0_{dec.depth}"]
+        for i, blk in enumerate(dec.blocks if not dense else ()):
             n = f"D{i}"
             xa = self._virt(d, d_ss) if d_ss is not None else d
             xin = F.interpolate(xa.to(dt), scale_factor=2, mode="nearest")
@@ -236,6 +255,54 @@ class Bf16TrainOracle:
     def _dgrad(self, conv, in_shape, dy):
         return conv2d_input(in_shape, self._w(conv), dy.to(self.dt), stride=conv.stride, padding=conv.padding)
 
+    @staticmethod
+    def _dense_order(dec):
+        """(node, lower node, names on its level) in forward order — the loops of smp UnetPlusPlusDecoder.forward (in-tree
+        twin: reference network/extra/efficientunetplusplus/decoder.py:156-184); f0 = deepest encoder feature"""
+        order, depth = [], dec.depth
+        for layer_idx in range(depth):
+            for depth_idx in range(depth - layer_idx):
+                if layer_idx == 0:
+                    order.append((f"x_{depth_idx}_{depth_idx}", f"f{depth_idx}", [f"f{depth_idx + 1}"]))
+                else:
+                    li = depth_idx + layer_idx
+                    cat = [f"x_{idx}_{li}" for idx in range(depth_idx + 1, li + 1)] + [f"f{li + 1}"]
+                    order.append((f"x_{depth_idx}_{li}", f"x_{depth_idx}_{li - 1}", cat))
+        order.append((f"x_0_{depth}", f"x_0_{depth - 1}", []))
+        return order
+
+    def _dense_backward(self, dec, S, g_head, skip_grads):
+        """reverse of the dense decoder with the HIP path's accumulation order (backward_bf16): blocks in reverse forward
+        order; a node's gradient collects, one rounding per contribution, the 2x2 sums of the block to its right and the
+        slices of the concatenated skips further right.  Fills skip_grads, returns the gradient of f0."""
+        dt = self.dt
+        G = {f"x_0_{dec.depth}": g_head}
+        for name, low, cat in reversed(self._dense_order(dec)):
+            blk, d, p, n = dec.blocks[name], S["P" + name], f"decoder.blocks.{name}", "P" + name
+            g = self._t(f"{n}.g", G.pop(name))
+            dy2, _ = self._bn_bwd(blk.conv2[1], f"{p}.conv2.1", g, d["y2"], d["ss2"], virtual=True)
+            dy2 = self._t(f"{n}.dy2", dy2)
+            z1 = self._virt(d["y1"], d["ss1"])
+            self._wgrad(blk.conv2[0], f"{p}.conv2.0.weight", z1, dy2)
+            dz1 = self._t(f"{n}.dz1", rbf(self._dgrad(blk.conv2[0], z1.shape, dy2)).to(dt))
+            dy1, _ = self._bn_bwd(blk.conv1[1], f"{p}.conv1.1", dz1, d["y1"], d["ss1"], virtual=True)
+            dy1 = self._t(f"{n}.dy1", dy1)
+            self._wgrad(blk.conv1[0], f"{p}.conv1.0.weight", d["xin"], dy1)
+            dxin = rbf(self._dgrad(blk.conv1[0], d["xin"].shape, dy1)).to(dt)
+            cx = d["cx"]
+            dskip = self._t(f"{n}.dskip", dxin[:, cx:].contiguous()) if cat else None
+            dup = self._t(f"{n}.dup", dxin[:, :cx].contiguous()).float()
+            quad = (dup[:, :, 0::2, 0::2] + dup[:, :, 0::2, 1::2]) + (dup[:, :, 1::2, 0::2] + dup[:, :, 1::2, 1::2])
+            G[low] = rbf(quad).to(dt) if low not in G else rbf(G[low].float() + quad).to(dt)
+            off = 0
+            for cname, Cn in zip(cat, d["widths"]):
+                part = dskip[:, off:off + Cn]
+                G[cname] = part.contiguous() if cname not in G else rbf(G[cname].float() + part.float()).to(dt)
+                off += Cn
+        for k in range(1, 5):
+            skip_grads[4 - k] = self._t(f"Pf{k}.g", G[f"f{k}"])
+        return self._t("Pf0.g", G["f0"])
+
     def _resunet_block_backward(self, blk, d, p, n, g, skip_grads, slot):
         """reverse of one ResUnet decoder block with the HIP path's rounding points (backward_bf16): both branches' data
         gradients are stored as bf16, added in fp32 and rounded once; then the 2x2 sums of the up-sampling"""
@@ -273,7 +340,10 @@ class Bf16TrainOracle:
         g = self._t("head.g", rbf(conv2d_input(hx.shape, head.weight.detach().to(dt), dl, padding=head.padding)).to(dt))
 
         skip_grads = [None] * 5
-        for i in range(4, -1, -1):
+        dense = isinstance(dec.blocks, torch.nn.ModuleDict)
+        if dense:
+            g = self._dense_backward(dec, S, g, skip_grads)
+        for i in (range(4, -1, -1) if not dense else ()):
             blk, d = dec.blocks[i], S[f"D{i}"]
             p, n = f"decoder.blocks.{i}", f"D{i}"
             if hasattr(blk, "identity_conv"):
