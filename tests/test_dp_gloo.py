@@ -103,7 +103,8 @@ def _gpu_worker(rank, world, port, q):
         dist.all_gather(ps, m.flat_params.data)
         ok_sync = torch.equal(ps[0], ps[1])                         # replicas stay identical after the update
         moved = not torch.equal(ps[0], p_solo)                      # and differ from the single-replica update
-        q.put((rank, bool(ok_sum), bool(ok_sync), bool(moved)))
+        q.put(("fp32", rank, bool(ok_sum), bool(ok_sync), bool(moved)))
+        _bf16_dp_case(rank, world, q)     # the same check under bf16 in the same pair of processes (a spawn costs ~10 s)
     finally:
         dist.destroy_process_group()
 
@@ -120,12 +121,18 @@ def test_data_parallel_step_equals_sum_of_replica_gradients():
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=500) for _ in procs]
+    res = [q.get(timeout=500) for _ in range(4)]
     for p in procs:
         p.join(60)
-    assert all(r[1] for r in res), "all-reduced gradient != sum of replica gradients"
-    assert all(r[2] for r in res), "replicas diverged"
-    assert all(r[3] for r in res)
+    f32 = [r for r in res if r[0] == "fp32"]
+    b16 = [r for r in res if r[0] == "bf16"]
+    assert len(f32) == 2 and len(b16) == 2
+    assert all(r[2] for r in f32), "all-reduced gradient != sum of replica gradients"
+    assert all(r[3] for r in f32), "replicas diverged"
+    assert all(r[4] for r in f32)
+    # HipTrainer(distributed=True, precision="bf16") (BASELINE configs[2] x configs[3])
+    assert all(r[2] for r in b16), "bf16: all-reduced gradient != sum of replica gradients"
+    assert all(r[3] for r in b16), "bf16: replicas diverged"
 
 
 def _nan_worker(rank, world, port, q, precisions):
@@ -193,53 +200,30 @@ def test_nonfinite_loss_on_one_rank_skips_the_step_on_all_ranks():
         assert synced and finite
 
 
-def _bf16_dp_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from deadtrees_amd.data.synthetic import synth_batch
-        from deadtrees_amd.network.unet import UNetHIP
-        from deadtrees_amd.trainer import HipTrainer
-        dev = "cuda:0"
-        torch.cuda.set_device(0)
-        img, mask = synth_batch(2, 64, 64, 3, 2, seed=90 + rank)
-        img, mask = img.to(dev), mask.to(dev)
-        solo = UNetHIP()
-        solo.reset_parameters(seed=3)
-        solo.to(dev)
-        HipTrainer(solo, precision="bf16").step(img, mask)
-        g_local = solo._grad_buffer().clone()
-        m = UNetHIP()
-        m.reset_parameters(seed=3)
-        m.to(dev)
-        tr = HipTrainer(m, distributed=True, precision="bf16")
-        tr.broadcast_parameters(0)
-        tr.step(img, mask)
-        gathered = [torch.empty_like(g_local) for _ in range(world)]
-        dist.all_gather(gathered, g_local)
-        ok_sum = torch.equal(m._grad_buffer(), gathered[0] + gathered[1])
-        ps = [torch.empty_like(m.flat_params.data) for _ in range(world)]
-        dist.all_gather(ps, m.flat_params.data)
-        q.put((rank, bool(ok_sum), bool(torch.equal(ps[0], ps[1]))))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.gpu
-@pytest.mark.timeout(600)
-def test_bf16_data_parallel_step_equals_sum_of_replica_gradients():
-    """the fp32 test above for ``HipTrainer(distributed=True, precision="bf16")`` (BASELINE configs[2] x configs[3])"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bf16_dp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=500) for _ in procs]
-    for p in procs:
-        p.join(60)
-    assert all(r[1] for r in res), "bf16: all-reduced gradient != sum of replica gradients"
-    assert all(r[2] for r in res), "bf16: replicas diverged"
+def _bf16_dp_case(rank, world, q):
+    from deadtrees_amd.data.synthetic import synth_batch
+    from deadtrees_amd.network.unet import UNetHIP
+    from deadtrees_amd.trainer import HipTrainer
+    dev = "cuda:0"
+    img, mask = synth_batch(2, 64, 64, 3, 2, seed=90 + rank)
+    img, mask = img.to(dev), mask.to(dev)
+    solo = UNetHIP()
+    solo.reset_parameters(seed=3)
+    solo.to(dev)
+    HipTrainer(solo, precision="bf16").step(img, mask)
+    g_local = solo._grad_buffer().clone()
+    m = UNetHIP()
+    m.reset_parameters(seed=3)
+    m.to(dev)
+    tr = HipTrainer(m, distributed=True, precision="bf16")
+    tr.broadcast_parameters(0)
+    tr.step(img, mask)
+    gathered = [torch.empty_like(g_local) for _ in range(world)]
+    dist.all_gather(gathered, g_local)
+    ok_sum = torch.equal(m._grad_buffer(), gathered[0] + gathered[1])
+    ps = [torch.empty_like(m.flat_params.data) for _ in range(world)]
+    dist.all_gather(ps, m.flat_params.data)
+    q.put(("bf16", rank, bool(ok_sum), bool(torch.equal(ps[0], ps[1]))))
 
 
 @pytest.mark.gpu
@@ -264,4 +248,5 @@ def test_bench_gpus_2_runs_as_typed():
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["global_batch"] == 4
     assert out["scaling"] == "weak" and out["value"] > 0 and out["allreduce_bytes_per_step"] == 4 * 24436516
     assert out["ms_per_step_rank_min"] <= out["ms_per_step_rank_max"]
-    assert 0 < out["roofline"]["frac"] <= 1.0 and out["roofline"]["kernels"]
+    # (a 64-pixel tile on two ranks sharing the GPU is launch-latency bound: the fraction can round to 0.0000)
+    assert 0 <= out["roofline"]["frac"] <= 1.0 and out["roofline"]["kernels"] and out["roofline"]["launches"] > 0

@@ -234,8 +234,14 @@ def test_ensemble_vote_matches_torch_mode(tmp_path):
     with pytest.raises(ValueError):
         PyTorchEnsembleInference(files[0], files[1])
     x = torch.randn((2, 4, 128, 128), generator=g)
-    ens = PyTorchEnsembleInference(*files).run(x, device=DEV).cpu()
-    singles = torch.stack([PyTorchInference(f).run(x, device=DEV).cpu() for f in files], dim=1)
+    ensemble = PyTorchEnsembleInference(*files)
+    ens = ensemble.run(x, device=DEV).cpu()
+    # the members' own maps: one checkpoint through PyTorchInference (the loader path), the other two straight from the
+    # ensemble's loaded models (each load + model build costs seconds of host time)
+    xs = x[:, :3].contiguous().to(DEV)
+    first = PyTorchInference(files[0]).run(x, device=DEV).cpu()
+    assert torch.equal(first, ensemble._models[0].predict_classes(xs).cpu())
+    singles = torch.stack([first] + [m.predict_classes(xs).cpu() for m in ensemble._models[1:]], dim=1)
     assert torch.equal(ens, torch.mode(singles, dim=1)[0])          # the reference's stack(dim=1) + mode(axis=1)
 
 
