@@ -108,6 +108,10 @@ SIGNATURES = {
     "dt_augment_labels": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_conv2d_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_conv2d_bf16_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
+    "dt_maxpool3x3s2_bwd_bn_rows": (C.c_int, [C.c_int] * 4),
+    "dt_maxpool3x3s2_bwd_bn": (C.c_int, [c_f, c_f, c_f, C.c_int, C.POINTER(BnBwdFuse), c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_maxpool3x3s2_bwd_bn_bf16_rows": (C.c_int, [C.c_int] * 4),
+    "dt_maxpool3x3s2_bwd_bn_bf16": (C.c_int, [c_f, c_f, c_f, C.c_int, C.POINTER(BnBwdFuse), c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_upsample2x_bwd_bn_rows": (C.c_int, [C.c_int] * 4),
     "dt_upsample2x_bwd_bn": (C.c_int, [c_f, c_f, C.POINTER(BnBwdFuse), c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "dt_conv2d_upsampled_dgrad_supported": (C.c_int, [_P]),

@@ -735,6 +735,102 @@ __global__ __launch_bounds__(256) void maxpool_bwd_quad_kernel(const f32x4* __re
   }
 }
 
+// the same pass with the BatchNorm-backward sums of the layer whose (virtual) activation was pooled (the stem) taken from the
+// gradient it writes: g = dx after the optional join, mask from y * scale + shift, sum g and sum g * xhat per channel; one
+// partial row per workgroup (fixed channel quad per thread: the grid stride is a multiple of C / 4) -> dt_bn_bwd_apply
+__global__ __launch_bounds__(256) void maxpool_bwd_quad_bn_kernel(const f32x4* __restrict__ dout,
+                                                                  const uint32_t* __restrict__ amax, f32x4* __restrict__ dx,
+                                                                  const f32x4* __restrict__ y, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ act_scale,
+                                                                  const float* __restrict__ act_shift, float* __restrict__ red,
+                                                                  int acc, int B, int H, int W, int C4, int Ho, int Wo, int P) {
+  __shared__ f32x4 sh[2][256];
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int t = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + t;
+  const int c4 = (int)(i0 % C4);
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+  const f32x4 asc = reinterpret_cast<const f32x4*>(act_scale)[c4], ash = reinterpret_cast<const f32x4*>(act_shift)[c4];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sg = z, sx = z;
+  for (int64_t i = i0; i < total; i += stride) {
+    int64_t r = i / C4;
+    const int p = (int)(r % Wo);
+    r /= Wo;
+    const int q = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const bool q1 = q + 1 < Ho, p1 = p + 1 < Wo;
+    const int64_t o00 = i, o01 = i + C4, o10 = i + (int64_t)Wo * C4, o11 = o10 + C4;
+    const f32x4 d00 = dout[o00], d01 = p1 ? dout[o01] : z, d10 = q1 ? dout[o10] : z, d11 = (q1 && p1) ? dout[o11] : z;
+    const uint32_t a00 = amax[o00], a01 = p1 ? amax[o01] : 0xffffffffu, a10 = q1 ? amax[o10] : 0xffffffffu,
+                   a11 = (q1 && p1) ? amax[o11] : 0xffffffffu;
+    f32x4 g[4] = {z, z, z, z};   // pixels (2q, 2p), (2q, 2p+1), (2q+1, 2p), (2q+1, 2p+1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t t00 = (a00 >> (8 * k)) & 0xffu, t01 = (a01 >> (8 * k)) & 0xffu, t10 = (a10 >> (8 * k)) & 0xffu,
+                     t11 = (a11 >> (8 * k)) & 0xffu;
+      if (t00 == 4u) g[0][k] += d00[k];
+      if (t00 == 5u) g[1][k] += d00[k];
+      if (t01 == 3u) g[1][k] += d01[k];
+      if (t00 == 7u) g[2][k] += d00[k];
+      if (t10 == 1u) g[2][k] += d10[k];
+      if (t00 == 8u) g[3][k] += d00[k];
+      if (t01 == 6u) g[3][k] += d01[k];
+      if (t10 == 2u) g[3][k] += d10[k];
+      if (t11 == 0u) g[3][k] += d11[k];
+    }
+    const int64_t x00 = (((int64_t)b * H + 2 * q) * W + 2 * p) * C4 + c4, x10 = x00 + (int64_t)W * C4;
+    const int64_t xs[4] = {x00, x00 + C4, x10, x10 + C4};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      f32x4 v = g[e];
+      if (acc) v = dx[xs[e]] + v;
+      dx[xs[e]] = v;
+      const f32x4 yv = y[xs[e]];
+      const f32x4 a = yv * asc + ash;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = a[k] > 0.f ? v[k] : 0.f;
+      sg += v;
+      sx += v * ((yv - mu) * is);
+    }
+  }
+  sh[0][t] = sg;
+  sh[1][t] = sx;
+  __syncthreads();
+  const int rl = t / C4, RL = 256 / C4;     // threads t, t + C4, ... share the channel quad
+  for (int s2 = RL >> 1; s2 >= 1; s2 >>= 1) {
+    if (rl < s2) {
+      sh[0][t] += sh[0][t + s2 * C4];
+      sh[1][t] += sh[1][t + s2 * C4];
+    }
+    __syncthreads();
+  }
+  if (t < C4) {
+    reinterpret_cast<f32x4*>(red)[(size_t)blockIdx.x * C4 + t] = sh[0][t];
+    reinterpret_cast<f32x4*>(red)[((size_t)P + blockIdx.x) * C4 + t] = sh[1][t];
+  }
+}
+
+extern "C" int dt_maxpool3x3s2_bwd_bn_rows(int B, int H, int W, int C) {
+  if (((H | W) & 1) != 0 || C <= 0 || (C & 3) != 0 || C / 4 > 256 || 256 % (C / 4) != 0) return 0;   // even maps only
+  return ew_grid((int64_t)B * (H / 2) * (W / 2) * (C / 4));
+}
+
+extern "C" int dt_maxpool3x3s2_bwd_bn(const float* dout, const uint8_t* argmax, float* dx, int accumulate,
+                                      const dt_bn_bwd_fuse* fuse, float* red, int B, int H, int W, int C, void* stream) {
+  DT_REQUIRE(dout && argmax && dx && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale &&
+                 fuse->act_shift && B > 0 && H > 0 && W > 0, "maxpool_bwd_bn: bad args");
+  const int P = dt_maxpool3x3s2_bwd_bn_rows(B, H, W, C);
+  DT_REQUIRE(P > 0, "maxpool_bwd_bn: even maps, C/4 a divisor of 256 (H=%d W=%d C=%d)", H, W, C);
+  hipLaunchKernelGGL(maxpool_bwd_quad_bn_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, (const f32x4*)dout,
+                     (const uint32_t*)argmax, (f32x4*)dx, (const f32x4*)fuse->y, fuse->mean, fuse->invstd, fuse->act_scale,
+                     fuse->act_shift, red, accumulate, B, H, W, C / 4, H / 2, W / 2, P);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 extern "C" int dt_maxpool3x3s2_bwd(const float* dout, const uint8_t* argmax, float* dx, int accumulate, int B,
                                    int H, int W, int C, void* stream) {
   DT_REQUIRE(dout && argmax && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "maxpool_bwd: bad args");

@@ -425,6 +425,127 @@ __global__ __launch_bounds__(256) void maxpool_bwd_bf16_quad_kernel(const bf16x8
   }
 }
 
+// with the BatchNorm-backward sums of the pooled layer (the stem) from the ROUNDED gradient it writes and the mask of
+// bf16(y * scale + shift), like bn_bwd_reduce_bf16_kernel (fp32 twin: maxpool_bwd_quad_bn_kernel)
+__global__ __launch_bounds__(256) void maxpool_bwd_bf16_quad_bn_kernel(const bf16x8* __restrict__ dout,
+                                                                       const uint2* __restrict__ amax, bf16x8* __restrict__ dx,
+                                                                       const bf16x8* __restrict__ y,
+                                                                       const float* __restrict__ mean,
+                                                                       const float* __restrict__ invstd,
+                                                                       const float* __restrict__ act_scale,
+                                                                       const float* __restrict__ act_shift,
+                                                                       float* __restrict__ red, int acc, int B, int H, int W,
+                                                                       int C8, int Ho, int Wo, int P) {
+  __shared__ float sh[16][256];
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;   // multiple of C8 (host check)
+  const int t = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + t;
+  const int c8 = (int)(i0 % C8);
+  float mu[8], is[8], asc[8], ash[8], sg[8], sx[8];
+  ldc8(mean, c8 * 8, mu);
+  ldc8(invstd, c8 * 8, is);
+  ldc8(act_scale, c8 * 8, asc);
+  ldc8(act_shift, c8 * 8, ash);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sg[k] = sx[k] = 0.f;
+  const uint2 none = make_uint2(0xffffffffu, 0xffffffffu);
+  for (int64_t i = i0; i < total; i += stride) {
+    int64_t rr = i / C8;
+    const int p = (int)(rr % Wo);
+    rr /= Wo;
+    const int q = (int)(rr % Ho);
+    const int b = (int)(rr / Ho);
+    const bool q1 = q + 1 < Ho, p1 = p + 1 < Wo;
+    const int64_t o00 = i, o01 = i + C8, o10 = i + (int64_t)Wo * C8, o11 = o10 + C8;
+    float d00[8], d01[8], d10[8], d11[8];
+    load8(dout, o00, d00);
+    load8(dout, p1 ? o01 : o00, d01);
+    load8(dout, q1 ? o10 : o00, d10);
+    load8(dout, (q1 && p1) ? o11 : o00, d11);
+    const uint2 a00 = amax[o00], a01 = p1 ? amax[o01] : none, a10 = q1 ? amax[o10] : none,
+                a11 = (q1 && p1) ? amax[o11] : none;
+    float g[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int shf = 8 * (k & 3);
+      const unsigned t00 = ((k < 4 ? a00.x : a00.y) >> shf) & 0xffu, t01 = ((k < 4 ? a01.x : a01.y) >> shf) & 0xffu,
+                     t10 = ((k < 4 ? a10.x : a10.y) >> shf) & 0xffu, t11 = ((k < 4 ? a11.x : a11.y) >> shf) & 0xffu;
+      float u00 = 0.f, u01 = 0.f, u10 = 0.f, u11 = 0.f;
+      if (t00 == 4u) u00 += d00[k];
+      if (t00 == 5u) u01 += d00[k];
+      if (t01 == 3u) u01 += d01[k];
+      if (t00 == 7u) u10 += d00[k];
+      if (t10 == 1u) u10 += d10[k];
+      if (t00 == 8u) u11 += d00[k];
+      if (t01 == 6u) u11 += d01[k];
+      if (t10 == 2u) u11 += d10[k];
+      if (t11 == 0u) u11 += d11[k];
+      g[0][k] = u00; g[1][k] = u01; g[2][k] = u10; g[3][k] = u11;
+    }
+    const int64_t x00 = (((int64_t)b * H + 2 * q) * W + 2 * p) * C8 + c8, x10 = x00 + (int64_t)W * C8;
+    const int64_t xs[4] = {x00, x00 + C8, x10, x10 + C8};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float prev[8], yv[8];
+      if (acc) load8(dx, xs[e], prev);
+      load8(y, xs[e], yv);
+      bf16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        o[k] = (__bf16)(acc ? prev[k] + g[e][k] : g[e][k]);
+        const float act = (float)(__bf16)(yv[k] * asc[k] + ash[k]);
+        const float gm = act > 0.f ? (float)o[k] : 0.f;
+        sg[k] += gm;
+        sx[k] += gm * ((yv[k] - mu[k]) * is[k]);
+      }
+      dx[xs[e]] = o;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sh[k][t] = sg[k];
+    sh[8 + k][t] = sx[k];
+  }
+  __syncthreads();
+  const int rl = t / C8, RL = 256 / C8;
+  for (int s2 = RL >> 1; s2 >= 1; s2 >>= 1) {
+    if (rl < s2) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sh[k][t] += sh[k][t + s2 * C8];
+    }
+    __syncthreads();
+  }
+  if (t < C8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[(size_t)blockIdx.x * C8 * 8 + t * 8 + k] = sh[k][t];
+      red[((size_t)P + blockIdx.x) * C8 * 8 + t * 8 + k] = sh[8 + k][t];
+    }
+  }
+}
+
+extern "C" int dt_maxpool3x3s2_bwd_bn_bf16_rows(int B, int H, int W, int C) {
+  if (((H | W) & 1) != 0 || C <= 0 || (C & 7) != 0 || C / 8 > 256 || 256 % (C / 8) != 0) return 0;   // even maps only
+  const int64_t g = ((int64_t)B * (H / 2) * (W / 2) * (C / 8) + 255) / 256;
+  return (int)(g > 4096 ? 4096 : (g > 0 ? g : 1));
+}
+
+extern "C" int dt_maxpool3x3s2_bwd_bn_bf16(const void* dout, const uint8_t* argmax, void* dx, int accumulate,
+                                           const dt_bn_bwd_fuse* fuse, float* red, int B, int H, int W, int C, void* stream) {
+  DT_REQUIRE(dout && argmax && dx && fuse && red && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale &&
+                 fuse->act_shift && B > 0 && H > 0 && W > 0, "maxpool_bwd_bn_bf16: bad args");
+  const int P = dt_maxpool3x3s2_bwd_bn_bf16_rows(B, H, W, C);
+  DT_REQUIRE(P > 0, "maxpool_bwd_bn_bf16: even maps, C/8 a divisor of 256 (H=%d W=%d C=%d)", H, W, C);
+  DT_REQUIRE((((uintptr_t)fuse->mean | (uintptr_t)fuse->invstd | (uintptr_t)fuse->act_scale | (uintptr_t)fuse->act_shift) & 15) == 0,
+             "maxpool_bwd_bn_bf16: per-channel arrays must be 16-byte aligned");
+  hipLaunchKernelGGL(maxpool_bwd_bf16_quad_bn_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)dout,
+                     (const uint2*)argmax, (bf16x8*)dx, (const bf16x8*)fuse->y, fuse->mean, fuse->invstd, fuse->act_scale,
+                     fuse->act_shift, red, accumulate, B, H, W, C / 8, H / 2, W / 2, P);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 extern "C" int dt_maxpool3x3s2_bwd_bf16(const void* dout, const uint8_t* argmax, void* dx, int accumulate, int B, int H,
                                         int W, int C, void* stream) {
   DT_REQUIRE(dout && argmax && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "maxpool_bwd_bf16: bad args");

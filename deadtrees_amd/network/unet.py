@@ -84,6 +84,7 @@ class UNetEngine:
         # tiles/s; DT_MATERIALIZE_Z1=0 restores the fused form (a gain with the direct kernels: +2 % in round 1)
         # inference (eval mode, nothing saved): BatchNorm + ReLU (+ residual) in the Winograd epilogue, DT_FUSE_EVAL=0 = A/B
         self._fuse_eval_opt = os.environ.get("DT_FUSE_EVAL", "1") != "0"
+        self._fuse_pool_bn = os.environ.get("DT_FUSE_POOL_BN", "1") != "0"   # stem BatchNorm-backward sums in the max-pool backward
         self._fuse_eval = False
         self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
         # the same for the decoder block outputs that feed a Winograd conv1 (716.6 vs 712.8 tiles/s)
@@ -1393,10 +1394,22 @@ class UNetEngine:
 
         pl, stem = S["pool"], S["stem"]
         gf1 = skip_grads[0]
-        _lib.check(lib.dt_maxpool3x3s2_bwd_bf16(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
-                   "dt_maxpool3x3s2_bwd_bf16")
+        stem_red = None
+        P = lib.dt_maxpool3x3s2_bwd_bn_bf16_rows(B, pl["H"], pl["W"], 64) if self._fuse_pool_bn else 0
+        if P > 0:      # even maps: the stem's BatchNorm-backward sums ride in the pass that writes its activation gradient
+            stq = sp.stem
+            red = self._buf("bn_red_pool", lib.dt_bn_stats_floats(P, 64), device=dev)
+            ssc, ssh = self._ss(stq, bnws)
+            fuse = _lib.BnBwdFuse(_p(stem["y"]), _p(bnws[stq.bn_off:stq.bn_off + 64]),
+                                  _p(bnws[nb + stq.bn_off:nb + stq.bn_off + 64]), _p(ssc), _p(ssh))
+            _lib.check(lib.dt_maxpool3x3s2_bwd_bn_bf16(_p(g), _p(pl["amax"]), _p(gf1), 1, C.byref(fuse), _p(red), B, pl["H"],
+                                                       pl["W"], 64, st), "dt_maxpool3x3s2_bwd_bn_bf16")
+            stem_red = (red, P)
+        else:
+            _lib.check(lib.dt_maxpool3x3s2_bwd_bf16(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
+                       "dt_maxpool3x3s2_bwd_bf16")
         self._tr("gf1", gf1)
-        dy = bn_bwd(sp.stem, gf1, None, stem["y"], virtual_act=True)
+        dy = bn_bwd(sp.stem, gf1, None, stem["y"], virtual_act=True, reduced=stem_red)
         self._tr("stem.dy", dy)
         stc = sp.stem
         if stem.get("s2d") is not None:
@@ -1839,9 +1852,21 @@ class UNetEngine:
         pl = S["pool"]
         stem = S["stem"]
         gf1 = skip_grads[0]
-        _lib.check(lib.dt_maxpool3x3s2_bwd(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
-                   "dt_maxpool3x3s2_bwd")
-        dy = self._bn_bwd(sp.stem, params, grads, bnws, gf1, None, stem["y"], virtual_act=True)
+        stem_red = None
+        P = lib.dt_maxpool3x3s2_bwd_bn_rows(B, pl["H"], pl["W"], 64) if (self._fuse_bn and self._fuse_pool_bn) else 0
+        if P > 0:      # even maps: the stem's BatchNorm-backward sums ride in the pass that writes its activation gradient
+            stc, nbq = sp.stem, sp.n_bn_channels
+            red = self._buf("bn_red_pool", lib.dt_bn_stats_floats(P, 64), device=dev)
+            ssc, ssh = self._ss(stc, bnws)
+            fuse = _lib.BnBwdFuse(_p(stem["y"]), _p(bnws[stc.bn_off:stc.bn_off + 64]),
+                                  _p(bnws[nbq + stc.bn_off:nbq + stc.bn_off + 64]), _p(ssc), _p(ssh))
+            _lib.check(lib.dt_maxpool3x3s2_bwd_bn(_p(g), _p(pl["amax"]), _p(gf1), 1, C.byref(fuse), _p(red), B, pl["H"], pl["W"],
+                                                  64, st), "dt_maxpool3x3s2_bwd_bn")
+            stem_red = (red, P)
+        else:
+            _lib.check(lib.dt_maxpool3x3s2_bwd(_p(g), _p(pl["amax"]), _p(gf1), 1, B, pl["H"], pl["W"], 64, st),
+                       "dt_maxpool3x3s2_bwd")
+        dy = self._bn_bwd(sp.stem, params, grads, bnws, gf1, None, stem["y"], virtual_act=True, reduced=stem_red)
         self._wgrad(sp.stem, grads, stem["x"], None, 0, B, stem["Hin"], stem["Win"], dy)
         self._join_side()
         if self.grad_hook:

@@ -425,6 +425,18 @@ int dt_conv2d_bf16_upsampled_dgrad_supported(const dt_conv_desc* desc);
 int dt_conv2d_bf16_upsampled_dgrad(const dt_conv_desc* desc, const void* dy, const void* w_bf16, void* gx, float* red,
                                    const dt_bn_bwd_fuse* fuse, void* stream);
 
+/* Max-pool 3x3 / 2 backward (dt_maxpool3x3s2_bwd / _bf16) with the BatchNorm-backward sums of the layer whose (virtual)
+ * activation was pooled — the stem — taken from the gradient the pass writes (after the optional join with the skip
+ * gradient already in dx): red[2][P][C], P = dt_maxpool3x3s2_bwd_bn[_bf16]_rows(...) (0: odd map or channel count not
+ * covered — use the plain pass + dt_bn_bwd_reduce), -> dt_bn_bwd_apply.  bf16: sums from the rounded gradient and the mask
+ * of bf16(y * scale + shift), like dt_bn_bwd_reduce_bf16. */
+int dt_maxpool3x3s2_bwd_bn_rows(int B, int H, int W, int C);
+int dt_maxpool3x3s2_bwd_bn(const float* dout, const uint8_t* argmax, float* dx, int accumulate, const dt_bn_bwd_fuse* fuse,
+                           float* red, int B, int H, int W, int C, void* stream);
+int dt_maxpool3x3s2_bwd_bn_bf16_rows(int B, int H, int W, int C);
+int dt_maxpool3x3s2_bwd_bn_bf16(const void* dout, const uint8_t* argmax, void* dx, int accumulate, const dt_bn_bwd_fuse* fuse,
+                                float* red, int B, int H, int W, int C, void* stream);
+
 /* Nearest x2 upsample backward (2x2 sums, like dt_upsample2x_bwd) with the BatchNorm-backward reduction of the layer
  * whose (virtual) activation was upsampled fused in: dx[B,H,W,C] is that layer's output gradient, fuse->y its raw
  * output; red[2][P][C], P = dt_upsample2x_bwd_bn_rows(...), holds dt_bn_stats_floats(P, C) floats -> dt_bn_bwd_apply.

@@ -559,3 +559,48 @@ def test_conv_gradient_join_with_fused_bn_backward_reduction(B, H, W, Cin, Cout)
     with pytest.raises(RuntimeError):          # a join needs the stored activation
         ops.conv2d_bn_bwd(xg, wg, nhwc(y), mean.to(DEV), invstd.to(DEV), act_scale=mean.to(DEV), act_shift=mean.to(DEV),
                           join_into=nhwc(base))
+
+
+@pytest.mark.parametrize("acc", [False, True])
+def test_maxpool_backward_with_fused_batchnorm_sums(acc):
+    """dt_maxpool3x3s2_bwd_bn: the gradient is bit-identical to dt_maxpool3x3s2_bwd, the partial rows sum to the
+    BatchNorm-backward reduction of the pooled layer over that gradient (mask from y * scale + shift) — fp32 and bf16"""
+    import ctypes as C
+    from deadtrees_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(31)
+    B, Cc, H, W = 2, 64, 20, 28
+    st = torch.cuda.current_stream().cuda_stream
+    yraw = torch.randn((B, H, W, Cc), generator=g)
+    sc, sh = 1 + 0.3 * torch.randn(Cc, generator=g), 0.2 * torch.randn(Cc, generator=g)
+    mu, istd = 0.1 * torch.randn(Cc, generator=g), 1 + 0.2 * torch.rand(Cc, generator=g)
+    x = F.relu(yraw * sc + sh)
+    coef = [t.to(DEV) for t in (mu, istd, sc, sh)]
+    for bf in (False, True):
+        dt = torch.bfloat16 if bf else torch.float32
+        xd = x.to(dt).to(DEV)
+        yd = yraw.to(dt).to(DEV)
+        pooled, am = (ops.maxpool3x3s2_bf16(xd) if bf else ops.maxpool3x3s2(xd))
+        dout = torch.randn(pooled.shape, generator=g).to(dt).to(DEV)
+        prev = torch.randn((B, H, W, Cc), generator=g).to(dt).to(DEV) if acc else None
+        want = (ops.maxpool3x3s2_bwd_bf16 if bf else ops.maxpool3x3s2_bwd)(dout, am, H, W, dx=None if prev is None else prev.clone())
+        rows_fn = lib.dt_maxpool3x3s2_bwd_bn_bf16_rows if bf else lib.dt_maxpool3x3s2_bwd_bn_rows
+        fn = lib.dt_maxpool3x3s2_bwd_bn_bf16 if bf else lib.dt_maxpool3x3s2_bwd_bn
+        P = rows_fn(B, H, W, Cc)
+        assert P > 0 and rows_fn(B, H + 1, W, Cc) == 0
+        red = torch.empty(lib.dt_bn_stats_floats(P, Cc), dtype=torch.float32, device=DEV)
+        dx = prev.clone() if acc else torch.empty((B, H, W, Cc), dtype=dt, device=DEV)
+        fuse = _lib.BnBwdFuse(yd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr())
+        _lib.check(fn(dout.data_ptr(), am.data_ptr(), dx.data_ptr(), 1 if acc else 0, C.byref(fuse), red.data_ptr(), B, H, W, Cc,
+                      st), "maxpool_bwd_bn")
+        assert torch.equal(dx, want)
+        r = red[:2 * P * Cc].view(2, P, Cc).double().sum(1).cpu()
+        y64, g64 = yd.double().cpu(), dx.double().cpu()
+        act = (yd.float().cpu() * sc + sh)
+        act = act.to(torch.bfloat16).float() if bf else act
+        gm = torch.where(act > 0, g64, torch.zeros((), dtype=torch.float64))
+        xhat = (y64 - mu.double()) * istd.double()
+        tol = 1e-4 * float(gm.abs().sum(dim=(0, 1, 2)).max())
+        np.testing.assert_allclose(r[0], gm.sum(dim=(0, 1, 2)), rtol=1e-4, atol=tol)
+        np.testing.assert_allclose(r[1], (gm * xhat).sum(dim=(0, 1, 2)), rtol=1e-4, atol=3 * tol)
