@@ -1130,7 +1130,9 @@ int dt_conv2d_narrow_launch_upc(const dt_conv_desc* d, const NarrowLeanArgs& a, 
   if (d->C0 == 16 && d->Cout == 16) return nl_launch_upc<1, 1>(a, total, tf, epi, st);
   if (d->C0 == 16) return nl_launch_upc<1, 2>(a, total, tf, epi, st);
   if (d->Cout == 16) return nl_launch_upc<2, 1>(a, total, tf, epi, st);
-  return nl_launch_upc<2, 2>(a, total, tf, epi, st);
+  // 32 -> 32 would need 256 weight registers (it spills): dt_conv2d_narrow_subpixel keeps that shape on the 9-tap kernel
+  dt_set_error("conv_narrow: no sub-pixel form for 32 -> 32 channels");
+  return DT_ENOSYS;
 }
 
 // ================================================================================================================
