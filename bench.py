@@ -532,6 +532,19 @@ def infer_bench(args, model, dev, world, rank, distributed, as_leg=False):
                     "kernels": kernels}
             if issued != 1.0:
                 roof["direct_equiv_TFLOPs"] = round(direct, 2)
+            # HBM bytes per launch from the PMC passes of this command (profiles/traffic_infer.json, scripts/profile_round.sh)
+            tfile = os.path.join(ROOT, "profiles", "traffic_infer.json")
+            if os.path.exists(tfile) and (B, S) == (64, 256):
+                try:
+                    tj = json.load(open(tfile))
+                    ent = tj.get(name) or next((v for k, v in sorted(tj.items())
+                                                if k.startswith(name[:-1] + ",") and isinstance(v, dict)), {})
+                    roof["traffic"] = ent.get("hbm_bytes_per_launch")
+                    if ent:
+                        roof["traffic_detail"] = {k: ent[k] for k in ("fetch_bytes_per_launch", "write_bytes_per_launch",
+                                                                       "read_shape", "write_shape") if k in ent}
+                except Exception:
+                    pass
     # PCIe-inclusive rate (never `value`): uint8 tiles from pinned host memory, uint8 class maps back, double-buffered
     # on a copy stream so transfers overlap the previous batch's kernels
     pcie = None

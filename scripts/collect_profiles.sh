@@ -13,6 +13,13 @@ cp $src/pmcf_bf16/*/*counter_collection.csv profiles/${rnd}_pmc_fetch_size_bf16.
 cp $src/pmcw_bf16/*/*counter_collection.csv profiles/${rnd}_pmc_write_size_bf16.csv
 cp $src/calf/*/*counter_collection.csv profiles/${rnd}_pmc_calib_fetch.csv
 cp $src/calw/*/*counter_collection.csv profiles/${rnd}_pmc_calib_write.csv
+if [ -d $src/pmcf_infer ]; then
+  cp $src/pmcf_infer/*/*counter_collection.csv profiles/${rnd}_pmc_fetch_size_infer.csv
+  cp $src/pmcw_infer/*/*counter_collection.csv profiles/${rnd}_pmc_write_size_infer.csv
+fi
 python scripts/pmc_calib_report.py profiles/${rnd}_pmc_calib_fetch.csv profiles/${rnd}_pmc_calib_write.csv
 python scripts/make_traffic_json.py profiles/${rnd}_pmc_fetch_size.csv profiles/${rnd}_pmc_write_size.csv \
     profiles/${rnd}_pmc_fetch_size_bf16.csv profiles/${rnd}_pmc_write_size_bf16.csv | tail -n 40
+if [ -f profiles/${rnd}_pmc_fetch_size_infer.csv ]; then
+  python scripts/make_traffic_json.py --out traffic_infer.json profiles/${rnd}_pmc_fetch_size_infer.csv profiles/${rnd}_pmc_write_size_infer.csv | tail -n 12
+fi

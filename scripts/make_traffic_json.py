@@ -54,11 +54,18 @@ def shapes_of(kernel: str):
 
 
 def main():
-    # one (fetch, write) pair per profiled command: fp32 first, then e.g. the bf16 leg's pair
+    # one (fetch, write) pair per profiled command: fp32 first, then e.g. the bf16 leg's pair; `--out <file>` writes another
+    # file than profiles/traffic.json (the inference leg's kernels partly carry the training kernels' names at other sizes)
+    argv = list(sys.argv)
+    out_name = "traffic.json"
+    if "--out" in argv:
+        i = argv.index("--out")
+        out_name = argv[i + 1]
+        del argv[i:i + 2]
     fetch, write = {}, {}
-    for k in range(1, len(sys.argv) - 1, 2):
-        fetch.update(per_kernel(sys.argv[k], "FETCH_SIZE"))
-        write.update(per_kernel(sys.argv[k + 1], "WRITE_SIZE"))
+    for k in range(1, len(argv) - 1, 2):
+        fetch.update(per_kernel(argv[k], "FETCH_SIZE"))
+        write.update(per_kernel(argv[k + 1], "WRITE_SIZE"))
     out = {}
     fac, fac_src = load_calibration()
     for name, (v, k) in fetch.items():
@@ -77,7 +84,7 @@ def main():
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 1 "
                     "--no-cpu-baseline`; raw counters x per-access-shape factors (" + fac_src + "); values include Infinity-Cache "
                     "hits (the counters sit on the L2's fabric side)")
-    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
+    json.dump(out, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1, sort_keys=True)
     for k in sorted(out):
         if k != "_note":
             print(k, out[k]["hbm_bytes_per_launch"])

@@ -16,6 +16,8 @@ DT_OVERLAP_WGRAD=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmcw_f
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmcf_bf16 -- python3 bench.py --precision bf16 --batch 64 --graph off $P > $out/pmcf_bf16.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmcw_bf16 -- python3 bench.py --precision bf16 --batch 64 --graph off $P > $out/pmcw_bf16.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/infer -- python3 bench.py --mode infer --size 256 --batch 64 --steps 10 --warmup 2 > $out/infer.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmcf_infer -- python3 bench.py --mode infer --size 256 --batch 64 --steps 2 --warmup 1 > $out/pmcf_infer.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmcw_infer -- python3 bench.py --mode infer --size 256 --batch 64 --steps 2 --warmup 1 > $out/pmcw_infer.log 2>&1
 # counter calibration on known-byte kernels (scripts/ubench/pmc_calib.hip, built in-tree before the call)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/calf -- scripts/ubench/pmc_calib > $out/calf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/calw -- scripts/ubench/pmc_calib > $out/calw.log 2>&1
