@@ -125,6 +125,7 @@ SIGNATURES = {
     "dt_stem_pack_weights_bf16": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_stem_unpack_wgrad": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_weight_images": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "dt_weight_images_bf16_all": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, c_f]),
     "dt_ensemble_vote": (C.c_int, [c_f, C.c_int, I64, C.c_int, c_f, c_f, c_f, c_f]),
     "dt_signed_distmap_workspace": (I64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "dt_signed_distmap": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),

@@ -764,6 +764,61 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const float* __restr
   }
 }
 
+// the four bf16 images a bf16 TRAINING step needs (modes 1, 2, 3, 4 of weight_images_kernel) from ONE read of the
+// parameters: four launches re-read the 98 MB of fp32 weights four times (4 x 74 us per step at 2 TB/s)
+__global__ __launch_bounds__(256) void weight_images_bf16_all_kernel(const float* __restrict__ params, __bf16* __restrict__ o_fwd,
+                                                                     __bf16* __restrict__ o_dgrad, __bf16* __restrict__ o_fwd_c,
+                                                                     __bf16* __restrict__ o_dgrad_c,
+                                                                     const int32_t* __restrict__ table, int n_layers) {
+  __shared__ float tile[32][33];
+  __shared__ int32_t row[5];
+  if (threadIdx.x == 0) {
+    int l = 0;
+    while (l + 1 < n_layers && table[(l + 1) * 5 + 4] <= (int)blockIdx.x) ++l;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) row[k] = table[l * 5 + k];
+  }
+  __syncthreads();
+  const int w_off = row[0], taps = row[1], Cin = row[2], Cout = row[3];
+  const int t = (int)blockIdx.x - row[4];
+  const int cob = (Cout + 31) / 32, cib = (Cin + 31) / 32;
+  const int tap = t / (cib * cob), ci0 = ((t / cob) % cib) * 32, co0 = (t % cob) * 32;
+  const float* w = params + w_off + (size_t)tap * Cin * Cout;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int ci = ci0 + i, co = co0 + tx;
+    tile[i][tx] = (ci < Cin && co < Cout) ? w[(size_t)ci * Cout + co] : 0.f;
+  }
+  __syncthreads();
+  const size_t ob = (size_t)w_off + (size_t)tap * Cin * Cout;                  // images in the tap order of the source
+  const size_t obf = (size_t)w_off + (size_t)(taps - 1 - tap) * Cin * Cout;    // data-gradient images: taps reversed
+  const bool chunked = ((Cin | Cout) & 31) == 0;
+  for (int i = ty; i < 32; i += 8) {
+    {   // [tap][co][ci]
+      const int co = co0 + i, ci = ci0 + tx;
+      if (ci < Cin && co < Cout) o_fwd[ob + (size_t)co * Cin + ci] = (__bf16)tile[tx][i];
+    }
+    {   // HWIO, taps reversed
+      const int ci = ci0 + i, co = co0 + tx;
+      if (ci < Cin && co < Cout) o_dgrad[obf + (size_t)ci * Cout + co] = (__bf16)tile[i][tx];
+    }
+    if (chunked) {   // [tap][K/32][N][32] for the LDS-DMA kernels
+      o_fwd_c[ob + ((size_t)(ci0 >> 5) * Cout + co0 + i) * 32 + tx] = (__bf16)tile[tx][i];
+      o_dgrad_c[obf + ((size_t)(co0 >> 5) * Cin + ci0 + i) * 32 + tx] = (__bf16)tile[i][tx];
+    }
+  }
+}
+
+extern "C" int dt_weight_images_bf16_all(const float* params, void* fwd, void* dgrad, void* fwd_chunked, void* dgrad_chunked,
+                                         const int32_t* table, int n_layers, int total_tiles, void* stream) {
+  DT_REQUIRE(params && fwd && dgrad && fwd_chunked && dgrad_chunked && table && n_layers > 0 && total_tiles > 0,
+             "weight_images_bf16_all: bad args");
+  hipLaunchKernelGGL(weight_images_bf16_all_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, params,
+                     (__bf16*)fwd, (__bf16*)dgrad, (__bf16*)fwd_chunked, (__bf16*)dgrad_chunked, table, n_layers);
+  DT_LAUNCH_CHECK();
+  return DT_OK;
+}
+
 extern "C" int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles,
                                 int mode, void* stream) {
   DT_REQUIRE(params && out && table && n_layers > 0 && total_tiles > 0 && mode >= 0 && mode <= 4,

@@ -84,6 +84,7 @@ class UNetEngine:
         # tiles/s; DT_MATERIALIZE_Z1=0 restores the fused form (a gain with the direct kernels: +2 % in round 1)
         # inference (eval mode, nothing saved): BatchNorm + ReLU (+ residual) in the Winograd epilogue, DT_FUSE_EVAL=0 = A/B
         self._fuse_eval_opt = os.environ.get("DT_FUSE_EVAL", "1") != "0"
+        self._bf16_images_fused = os.environ.get("DT_BF16_IMAGES_FUSED", "1") != "0"   # four bf16 weight images in one launch
         self._fuse_pool_bn = os.environ.get("DT_FUSE_POOL_BN", "1") != "0"   # stem BatchNorm-backward sums in the max-pool backward
         self._fuse_eval = False
         self._mat_z1 = os.environ.get("DT_MATERIALIZE_Z1", "1" if self.winograd else "0") != "0"
@@ -680,6 +681,25 @@ class UNetEngine:
         self._ws[name + "_key"], self._ws[name] = key, buf
         return buf
 
+    def _bf16_weights_all(self, params: torch.Tensor):
+        """the four bf16 images a training step reads (forward / data gradient, plain / chunked) in ONE launch — one read of
+        the fp32 parameters instead of four; fills the caches _bf16_weights() looks at"""
+        key = (params.data_ptr(), params._version, self._weights_epoch)
+        names = ("bf16_w", "bf16_wd", "bf16_wc", "bf16_wdc")
+        if all(self._ws.get(n + "_key") == key for n in names):
+            return
+        bufs = []
+        for n in names:
+            b = self._ws.get(n)
+            if b is None or b.device != params.device:
+                b = torch.empty(self.spec.n_params, dtype=torch.bfloat16, device=params.device)
+            bufs.append(b)
+        tab, nl, tiles = self._weight_table(params.device)
+        _lib.check(self.lib.dt_weight_images_bf16_all(_p(params), _p(bufs[0]), _p(bufs[1]), _p(bufs[2]), _p(bufs[3]), _p(tab), nl,
+                                                      tiles, _stream()), "dt_weight_images_bf16_all")
+        for n, b in zip(names, bufs):
+            self._ws[n + "_key"], self._ws[n] = key, b
+
     def _bf16_mt(self, desc) -> int:
         """kernel family dt_conv2d_bf16 picks for `desc`: 8 = LDS-DMA staged (conv_bf16_dma.hip), 16 = lean narrow-layer
         kernel (conv_bf16_narrow.hip), else the register-staged kernels' tile multiplier"""
@@ -902,6 +922,8 @@ class UNetEngine:
             raise RuntimeError(f"bad input {tuple(x_nchw.shape)}")
         dev, st, bf = x_nchw.device, _stream(), torch.bfloat16
         self._bn_epoch += 1          # running statistics are rewritten on the device (invalidates cached eval affines)
+        if self._bf16_images_fused:
+            self._bf16_weights_all(params)
         wb = self._bf16_weights(params)
         wbc = self._bf16_weights(params, chunked=True)
         sv = _Saved()

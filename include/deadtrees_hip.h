@@ -396,6 +396,10 @@ int dt_channel_slice_bf16(const void* src, void* dst, int64_t n_pix, int C_narro
  * dt_conv2d_bf16_config: pass THAT image to such a launch); layers with K or N not a multiple of 32 are skipped. */
 int dt_weight_images(const float* params, void* out, const int32_t* table, int n_layers, int total_tiles, int mode,
                      void* stream);
+/* modes 1 - 4 (the four bf16 images of a bf16 training step: forward / data-gradient, plain / chunked for the LDS-DMA
+ * kernels) from one read of the parameters, each into its own n_params-element buffer */
+int dt_weight_images_bf16_all(const float* params, void* fwd, void* dgrad, void* fwd_chunked, void* dgrad_chunked,
+                              const int32_t* table, int n_layers, int total_tiles, void* stream);
 
 /* The 7x7 / stride-2 stem on the bf16 convolution kernels (smp encoder conv1, reached from network/segmodel.py:214):
  * dt_stem_s2d_bf16 turns the fp32 NHWC image [B,H,W,Cin<=4] into its 2x2 space-to-depth form [B,H/2,W/2,16] bf16
