@@ -362,7 +362,8 @@ class Bf16TrainOracle:
             cx = d["cx"]
             cv = blk.conv1[0]
             if (dxin_acc.shape[1] == cx and i >= 1 and cv.in_channels in (16, 32) and cv.out_channels in (16, 32)
-                    and dy1.shape[3] >= 32 and dy1.shape[2] >= 8):
+                    and dy1.shape[3] >= 32 and dy1.shape[2] >= 8
+                    and (self.forced is None or f"{n}.dup" not in self.forced)):   # (DT_BF16_FUSE_UPSAMPLE_BWD=0: the chain)
                 # the narrow layer without a skip (dec4.conv1): the HIP path takes the 2x2 sums of the up-sampling's backward
                 # on the fp32 accumulators of the data gradient (dt_conv2d_bf16_upsampled_dgrad) — ONE rounding, no
                 # full-resolution gradient tensor
