@@ -50,7 +50,11 @@ __device__ __forceinline__ void ww_static_for(F&& f) {
   }
 }
 
-template <bool TF>
+// CO32: a layer with 32 output channels (dec3.conv1: 128 -> 32): one 32-channel co block.  The two waves of a ci half
+// (wn = 0, 1) would multiply the same 32 x 32 block twice, so they split the chunk's K instead — wave wn takes k-steps
+// 2 wn, 2 wn + 1 of every position (32 MFMAs per chunk, the staging work of two of the 64-slot schedule's slots behind each)
+// — and write their accumulators as two partial slabs (part 2 split + wn) for the existing fixed-order reduction.
+template <bool TF, bool CO32 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWgArgs a) {
   __shared__ __attribute__((aligned(1024))) float lds[4 * WW_BUF + (TF ? 2 * WW_TF_MAXC : 4)];
   float* Vb = lds;                 // [2][WW_BUF] transformed input patches
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
   bool xcok[4], gcok[2];
   const unsigned xpix = (unsigned)Cs * 4u, xpitch = (unsigned)(Ws * Cs) * 4u;           // bytes per source pixel / row
   const unsigned gpix = (unsigned)a.Cout * 4u, gpitch = (unsigned)(a.Win * a.Cout) * 4u;
-  const unsigned xlane = (unsigned)(cbase + 2 * c2) * 4u, glane = (unsigned)(co0 + 2 * c2) * 4u;
+  const unsigned xlane = (unsigned)(cbase + 2 * c2) * 4u;
+  const unsigned glane = (CO32 && c2 >= 16) ? WW_OOB : (unsigned)(co0 + 2 * c2) * 4u;   // CO32: channels 32 .. 63 do not exist
   // offsets of the tile (l_b, l_ty, l_tx); 24-bit multiplies (full rate): row indices and pitches are < 2^24 (host check)
   auto prep_rows = [&]() {
     const bool live = l_b < a.B;
@@ -271,8 +276,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
     g_write(S0{}, Wb, i);
   }
 
-  const int aoff = kh * 256 + 32 * wm + r;   // + pos * 512 + step * 64
-  const int boff = kh * 256 + 32 * wn + r;
+  const int aoff = kh * 256 + 32 * wm + r + (CO32 ? 128 * wn : 0);   // + pos * 512 + step * 64 (CO32: k-steps 2 wn, 2 wn + 1)
+  const int boff = kh * 256 + (CO32 ? 128 * wn : 32 * wn) + r;
 
   // ---- one chunk (8 tiles = 4 k-steps x 2 halves): 16 positions x 4 k-steps = 64 MFMAs of 64 cycles; PAR = chunk & 1:
   // images PAR are multiplied, images PAR^1 receive chunk c+1 (from register set PAR^1), register set PAR is loaded
@@ -284,20 +289,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
     const float* Wc = Wb + PAR * WW_BUF + boff;
     float* Vn = Vb + (PAR ^ 1) * WW_BUF;
     float* Wn = Wb + (PAR ^ 1) * WW_BUF;
-    float fa[2][4], fb[2][4];
+    constexpr int NJ = CO32 ? 2 : 4;                    // k-steps of a position this wave multiplies
+    float fa[2][NJ], fb[2][NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       fa[0][j] = Vc[j * 64];
       fb[0][j] = Wc[j * 64];
     }
-    ww_static_for<0, 64>([&](auto kc) {
+    auto slot_work = [&](auto kc) {                     // the staging work of slot k of the 64-slot schedule
       constexpr int k = decltype(kc)::value;
-      constexpr int p = k >> 2, j = k & 3, cur = p & 1;
-      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j], acc[p], 0, 0, 0);
-      if (p + 1 < 16) {   // the next position's k-step j
-        fa[cur ^ 1][j] = Vc[(p + 1) * 512 + j * 64];
-        fb[cur ^ 1][j] = Wc[(p + 1) * 512 + j * 64];
-      }
       if (k == 1) prep_chunk(par_tag);                  // chunk c+2: offsets, then one load per slot
       if (k >= 2 && k < 22) load_one(par_tag, k - 2);
       if (k == 52) advance_tile();
@@ -306,6 +306,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
       if (k >= 39 && k < 43) x_col(SN{}, k - 39);
       if (k >= 43 && k < 47) x_row_write(Vn, k - 43);
       if (k >= 47 && k < 51) g_write(SN{}, Wn, k - 47);
+    };
+    ww_static_for<0, 16 * NJ>([&](auto mc) {
+      constexpr int mslot = decltype(mc)::value;
+      constexpr int p = mslot / NJ, j = mslot % NJ, cur = p & 1;
+      acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][j], acc[p], 0, 0, 0);
+      if (p + 1 < 16) {   // the next position's k-step j
+        fa[cur ^ 1][j] = Vc[(p + 1) * 512 + j * 64];
+        fb[cur ^ 1][j] = Wc[(p + 1) * 512 + j * 64];
+      }
+      if constexpr (CO32) {
+        slot_work(std::integral_constant<int, 2 * mslot>{});
+        slot_work(std::integral_constant<int, 2 * mslot + 1>{});
+      } else {
+        slot_work(mc);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of chunk c+2 (issued >= 58 MFMAs ago)
@@ -320,8 +335,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_wgrad_kernel(const WinoWg
 
   // ---- partial dU block -> workspace [split][block][pos][64 ci][64 co]
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws, 0, a.wsbytes, 0x00020000);
-  const unsigned lane_base = (unsigned)(((32 * wm + 4 * kh) * 64 + 32 * wn + r) * 4);
-  const int wg_base = (split * nblocks + blk) * (16 * 4096 * 4);
+  const unsigned lane_base = (unsigned)(((32 * wm + 4 * kh) * 64 + (CO32 ? 0 : 32 * wn) + r) * 4);
+  const int wg_base = ((CO32 ? 2 * split + wn : split) * nblocks + blk) * (16 * 4096 * 4);   // CO32: columns 32 .. 63 stay unwritten
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
 #pragma unroll
@@ -355,6 +370,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_final_kernel(const float* __re
   const int blk = blockIdx.y;
   const int e = blockIdx.x * 256 + threadIdx.x;   // 0..4095 inside the block
   const int ci = (blk / co_blocks) * 64 + (e >> 6), co = (blk % co_blocks) * 64 + (e & 63);
+  if (co >= Cout) return;   // the 32-channel layers' blocks are half-filled
   const int64_t n = (int64_t)ci_blocks * co_blocks * 16 * 4096;
   float u[16];
 #pragma unroll
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_final_kernel(const float* __re
 
 // ---------------------------------------------------------------- host side
 struct WwCfg {
-  int tiles_x, tiles_y, T, ci_blocks, co_blocks, ksplit, cps, rb, groups;
+  int tiles_x, tiles_y, T, ci_blocks, co_blocks, ksplit, cps, rb, groups, parts;
 };
 
 static WwCfg ww_cfg(const dt_conv_desc* d) {
@@ -394,7 +410,7 @@ static WwCfg ww_cfg(const dt_conv_desc* d) {
   c.tiles_y = dt_cdiv(d->Hin, 2);
   c.T = d->B * c.tiles_x * c.tiles_y;
   c.ci_blocks = (d->C0 + d->C1) / 64;
-  c.co_blocks = d->Cout / 64;
+  c.co_blocks = d->Cout == 32 ? 1 : d->Cout / 64;
   const int nblocks = c.ci_blocks * c.co_blocks;
   const int chunks = dt_cdiv(c.T, 8);
   int ks = WW_MAX_WGS / nblocks;
@@ -402,15 +418,24 @@ static WwCfg ww_cfg(const dt_conv_desc* d) {
   if (ks > dt_cdiv(chunks, 2)) ks = dt_cdiv(chunks, 2);
   c.cps = 2 * dt_cdiv(chunks, 2 * ks);          // even number of chunks per split
   c.ksplit = dt_cdiv(chunks, c.cps);
-  c.rb = c.ksplit > 16 ? dt_cdiv(c.ksplit, 16) : 1;
-  c.groups = dt_cdiv(c.ksplit, c.rb);
+  c.parts = d->Cout == 32 ? 2 * c.ksplit : c.ksplit;   // partial slabs (32-channel layers: two K halves per split)
+  c.rb = c.parts > 16 ? dt_cdiv(c.parts, 16) : 1;
+  c.groups = dt_cdiv(c.parts, c.rb);
   return c;
+}
+
+static bool ww_co32(const dt_conv_desc* d) {   // 32 output channels: the K-split form (DT_FP32_WINO_WGRAD_CO32=0 switches it off)
+  static const int on = [] {
+    const char* e = getenv("DT_FP32_WINO_WGRAD_CO32");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  return on && d->Cout == 32;
 }
 
 extern "C" int dt_conv2d_wgrad_winograd_supported(const dt_conv_desc* d) {
   if (d == nullptr) return 0;
   if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->mode0 == 2) return 0;
-  if ((d->C0 % 64) != 0 || (d->C1 % 64) != 0 || (d->Cout % 64) != 0 || d->C0 > WW_TF_MAXC) return 0;
+  if ((d->C0 % 64) != 0 || (d->C1 % 64) != 0 || ((d->Cout % 64) != 0 && !ww_co32(d)) || d->C0 > WW_TF_MAXC) return 0;
   if (d->Ho != d->Hin || d->Wo != d->Win) return 0;
   const size_t px0 = (size_t)d->B * (d->mode0 ? (d->Hin / 2) * (size_t)(d->Win / 2) : (size_t)d->Hin * d->Win);
   if (px0 * d->C0 * 4 >= 0x80000000ull || (size_t)d->B * d->Hin * d->Win * d->C1 * 4 >= 0x80000000ull) return 0;
@@ -422,7 +447,7 @@ extern "C" size_t dt_conv2d_wgrad_winograd_workspace(const dt_conv_desc* d) {
   if (!dt_conv2d_wgrad_winograd_supported(d)) return 0;
   const WwCfg c = ww_cfg(d);
   const size_t slab = (size_t)c.ci_blocks * c.co_blocks * 16 * 4096 * 4;
-  return slab * c.ksplit + (c.rb > 1 ? slab * c.groups : 0);
+  return slab * c.parts + (c.rb > 1 ? slab * c.groups : 0);
 }
 
 extern "C" int dt_conv2d_wgrad_winograd(const dt_conv_desc* d, const float* src0, const float* src1, const float* dy,
@@ -435,7 +460,7 @@ extern "C" int dt_conv2d_wgrad_winograd(const dt_conv_desc* d, const float* src0
   DT_REQUIRE(workspace_bytes >= dt_conv2d_wgrad_winograd_workspace(d), "wgrad_winograd: workspace too small");
   const WwCfg c = ww_cfg(d);
   const size_t slab = (size_t)c.ci_blocks * c.co_blocks * 16 * 4096 * 4;
-  DT_REQUIRE(slab * c.ksplit < 0x100000000ull, "wgrad_winograd: workspace beyond 4 GiB");
+  DT_REQUIRE(slab * c.parts < 0x100000000ull, "wgrad_winograd: workspace beyond 4 GiB");
   WinoWgArgs a;
   a.src0 = src0; a.src1 = src1; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.ws = workspace;
   a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = d->C1; a.mode0 = d->mode0; a.Cout = d->Cout;
@@ -445,19 +470,22 @@ extern "C" int dt_conv2d_wgrad_winograd(const dt_conv_desc* d, const float* src0
   a.bytes0 = (unsigned)(px0 * d->C0 * 4);
   a.bytes1 = (unsigned)((size_t)d->B * d->Hin * d->Win * d->C1 * 4);
   a.dybytes = (unsigned)((size_t)d->B * d->Ho * d->Wo * d->Cout * 4);
-  a.wsbytes = (unsigned)(slab * c.ksplit);
+  a.wsbytes = (unsigned)(slab * c.parts);
   hipStream_t st = (hipStream_t)stream;
   dim3 g((unsigned)(c.ci_blocks * c.co_blocks * c.ksplit)), blk(256);
-  if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<true>), g, blk, 0, st, a);
+  if (d->Cout == 32) {
+    if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<true, true>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<false, true>), g, blk, 0, st, a);
+  } else if (in_scale != nullptr) hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<true>), g, blk, 0, st, a);
   else hipLaunchKernelGGL((conv3x3_wino_wgrad_kernel<false>), g, blk, 0, st, a);
   DT_LAUNCH_CHECK();
   const float* parts_src = workspace;
-  int parts = c.ksplit;
+  int parts = c.parts;
   if (c.rb > 1) {
-    float* ws2 = workspace + slab / 4 * c.ksplit;
+    float* ws2 = workspace + slab / 4 * c.parts;
     const int64_t n4 = (int64_t)(slab / 16);
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)dt_cdiv(n4, 256), (unsigned)c.groups), dim3(256), 0, st,
-                       workspace, ws2, n4, c.ksplit, c.rb);
+                       workspace, ws2, n4, c.parts, c.rb);
     DT_LAUNCH_CHECK();
     parts_src = ws2;
     parts = c.groups;

@@ -197,7 +197,9 @@ def test_winograd_weight_images_of_a_network_match_the_per_layer_transform():
 
 WG_CASES = [  # B, H, W (stored size of source 0), C0, C1, mode0, Cout, transform
     (2, 32, 32, 64, 0, 0, 64, False), (1, 34, 70, 128, 0, 0, 64, True), (3, 17, 33, 64, 0, 0, 128, False),
-    (2, 16, 20, 64, 64, 1, 128, True), (4, 64, 64, 64, 0, 0, 64, False), (2, 16, 16, 512, 0, 0, 512, False)]
+    (2, 16, 20, 64, 64, 1, 128, True), (4, 64, 64, 64, 0, 0, 64, False), (2, 16, 16, 512, 0, 0, 512, False),
+    # 32 output channels (dec3.conv1: up(64) + skip(64) -> 32): one co block, the two waves of a ci half split the chunk's K
+    (2, 16, 20, 64, 64, 1, 32, True), (3, 17, 33, 64, 0, 0, 32, False), (4, 64, 64, 128, 0, 0, 32, False)]
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,mode0,Cout,tf", WG_CASES)
