@@ -56,6 +56,9 @@ struct WinoArgs {
   int B, Hin, Win, C0, C1, mode0;
   int Cout, cout_split, accumulate;
   int tiles_x, tiles_y, n_tiles, P, nchunks;
+  int nt0;                   // first 64-channel block of this launch (n_tiles counts the blocks it covers); 0 except for the
+                             // two launches of dt_conv2d_winograd_upsampled_dgrad
+  int stat_ld;               // row length of the statistics buffer (Cout; the up-sampled part's width in EPI 6)
   int pstats;                // 1: BatchNorm partial sums accumulated over the workgroup's tiles, ONE row per workgroup
   int pack;                  // 1: maps of at most 8x8 pixels — FOUR images share a 16x16-pixel tile (one per 8x8 quadrant)
   unsigned bytes0, bytes1;   // sizes of the two sources (buffer descriptors: out-of-range loads return 0)
@@ -79,6 +82,10 @@ __device__ __forceinline__ void wn_dma16(const void* g, void* l) {
 
 // EPI: 0 store (+ BatchNorm statistics, split outputs); 1 store + fused BatchNorm-backward sums (virtual activation);
 //      2 gradient join (out0 += ...); 3 join + BatchNorm-backward sums (stored activation);
+//      6 data gradient of a convolution whose first cout_split input channels were a nearest x2 up-sampling (decoder conv1):
+//        the 2x2 outputs of a Winograd tile ARE one source pixel's four gradients — their sum (a + b) + (c + d) is stored at
+//        half resolution [B, Hin/2, Win/2, cout_split] with the BatchNorm-backward sums of the layer below (virtual
+//        activation): a quarter of the stores, no full-resolution gradient, no dt_upsample2x_bwd_bn pass
 //      4 inference: out = relu(conv * scale + shift) (eval-mode BatchNorm + ReLU applied to the accumulators: the raw
 //        output is never stored and no elementwise pass follows); 5 the same with a residual: relu(conv * scale + shift + res)
 //
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   unsigned u_voff = 0;
   auto set_ug = [&](int round) {
     const int tile = tile_of_round(round < my_tiles ? round : 0);   // past the end: any valid address (never multiplied)
-    u_voff = (unsigned)((tile % a.n_tiles) * 64 + lane) * 16u;
+    u_voff = (unsigned)((tile % a.n_tiles + a.nt0) * 64 + lane) * 16u;
   };
   auto dma_plane = [&](float* Ud, int i) {
     const int plane = wave_u * 8 + i;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     // everything derived from the tile index is wave-uniform; say so, or hipcc wraps each of the 64 buffer stores in a
     // waterfall loop (readfirstlane / compare / saveexec per store: the scalar-offset operand must be provably uniform)
     const int tile = __builtin_amdgcn_readfirstlane(tile_of_round(round));
-    const int nt = tile % a.n_tiles, sp = tile / a.n_tiles;
+    const int nt = tile % a.n_tiles + a.nt0, sp = tile / a.n_tiles;
     const int tx = sp % a.tiles_x, ty = (sp / a.tiles_x) % a.tiles_y, b = sp / tiles_per_img;
     const int oy0 = PACK ? 0 : 16 * ty, ox0 = PACK ? 0 : 16 * tx, n0 = 64 * nt;
     const int n = n0 + 32 * wn + r;
@@ -381,10 +388,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     }
     float s1 = 0.f, s2 = 0.f;
     float b_mu = 0.f, b_is = 0.f, b_sc = 0.f, b_sh = 0.f;
-    if constexpr (EPI == 1 || EPI == 3) {
+    if constexpr (EPI == 1 || EPI == 3 || EPI == 6) {
       b_mu = a.bnb.mean[n];
       b_is = a.bnb.invstd[n];
-      if constexpr (EPI == 1) {
+      if constexpr (EPI == 1 || EPI == 6) {
         b_sc = a.bnb.act_scale[n];
         b_sh = a.bnb.act_shift[n];
       }
@@ -411,6 +418,51 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     const unsigned lane_base = (unsigned)((PACK ? kh * img_px4 : 8 * kh * ld4) + nn * 4);
     const int xlane = PACK ? 0 : ox0 + 8 * kh, ybase = PACK ? 0 : oy0 + 8 * wave_m;
     const bool img_ok = !PACK || 4 * sp + 2 * wave_m + kh < a.B;
+    if constexpr (EPI == 6) {
+      // half-resolution addressing: source pixel (oy0 / 2 + 4 wave_m + (i >> 2), ox0 / 2 + 4 kh + (i & 3)), channel nn of
+      // cout_split; y of the fused sums has the same layout.  Out-of-range pixels: WN_OOB (loads 0, store dropped).
+      const int Hs = a.Hin >> 1, Ws = a.Win >> 1;
+      const int ldl4 = __builtin_amdgcn_readfirstlane(ld * 4), rowl4 = __builtin_amdgcn_readfirstlane(Ws * ld * 4);
+      const int lbase = __builtin_amdgcn_readfirstlane(((b * Hs + (oy0 >> 1) + 4 * wave_m) * Ws + (ox0 >> 1)) * ld * 4);
+      const unsigned llane = (unsigned)(4 * kh * ldl4 + nn * 4);
+      const unsigned lbytes = (unsigned)((size_t)a.B * Hs * Ws * ld * 4);
+      const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, lbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsyl = __builtin_amdgcn_make_buffer_rsrc((void*)a.bnb.y, 0, lbytes, 0x00020000);
+      const int ysrc = (oy0 >> 1) + 4 * wave_m, xsrc = (ox0 >> 1) + 4 * kh;
+#pragma unroll
+      for (int qr = 0; qr < 4; ++qr) {
+        unsigned off[4];
+        int soff[4];
+        float yv[4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = 4 * qr + ii;
+          const bool ok = ysrc + (i >> 2) < Hs && xsrc + (i & 3) < Ws;
+          off[ii] = ok ? llane : WN_OOB;
+          soff[ii] = lbase + (i >> 2) * rowl4 + (i & 3) * ldl4;
+          yv[ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsyl, off[ii], soff[ii], 0));
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = 4 * qr + ii;
+          float t0[4], t1[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t0[j] = acc[0 + j][i] + acc[4 + j][i] + acc[8 + j][i];
+            t1[j] = acc[4 + j][i] - acc[8 + j][i] - acc[12 + j][i];
+          }
+          const float y0 = t0[0] + t0[1] + t0[2], y1 = t0[1] - t0[2] - t0[3];
+          const float y2 = t1[0] + t1[1] + t1[2], y3 = t1[1] - t1[2] - t1[3];
+          const float v = (y0 + y1) + (y2 + y3);                    // dt_upsample2x_bwd's order: (a + b) + (c + d)
+          const bool ok = off[ii] != WN_OOB;
+          const float g = (ok && (yv[ii] * b_sc + b_sh) > 0.f) ? v : 0.f;
+          s1 += g;
+          s2 += g * ((yv[ii] - b_mu) * b_is);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsl, off[ii], soff[ii], 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
 #pragma unroll
     for (int qr = 0; qr < 4; ++qr) {
       // 4 accumulator rows (4 Winograd tiles x 4 pixels) at a time: the reads of this quarter are in flight while its
@@ -501,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (tid < 128) {
         const int which = tid >> 6, c = tid & 63;
-        a.stats[((size_t)which * a.P + sp) * a.Cout + n0 + c] = red[which * 128 + c] + red[which * 128 + 64 + c];
+        a.stats[((size_t)which * a.P + sp) * a.stat_ld + n0 + c] = red[which * 128 + c] + red[which * 128 + 64 + c];
       }
       // the next step's barrier orders these reads of `red` before the next tile's writes
     }
@@ -524,7 +576,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
   // check: 32 % n_tiles == 0), so the sums stayed in registers; the other channel blocks of the row are written as zeros
   // (the finalize pass then reads <= 256 rows: no separate row-reduction launch)
   if (a.stats != nullptr && a.pstats) {
-    const int nt0 = tile_of_round(0) % a.n_tiles;
+    const int nt0 = tile_of_round(0) % a.n_tiles;   // (pstats launches start at channel block 0: a.nt0 == 0)
     const float u1 = ps1 + __shfl_xor(ps1, 32, 64);
     const float u2 = ps2 + __shfl_xor(ps2, 32, 64);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -535,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (tid < 128) {
       const int which = tid >> 6, c = tid & 63;
-      float* row = a.stats + ((size_t)which * a.P + blockIdx.x) * a.Cout;
+      float* row = a.stats + ((size_t)which * a.P + blockIdx.x) * a.stat_ld;
       for (int cb = 0; cb < a.n_tiles; ++cb)
         row[64 * cb + c] = cb == nt0 ? red[which * 128 + c] + red[which * 128 + 64 + c] : 0.f;
     }
@@ -663,6 +715,8 @@ int dt_conv_wino_launch(const dt_conv_desc* d, const float* src0, const float* s
   a.tiles_x = dt_cdiv(d->Wo, 16);
   a.tiles_y = dt_cdiv(d->Ho, 16);
   a.n_tiles = d->Cout / 64;
+  a.nt0 = 0;
+  a.stat_ld = d->Cout;
   a.pack = wn_pack(d);
   a.P = a.pack ? dt_cdiv(d->B, 4) : d->B * a.tiles_x * a.tiles_y;
   const int sp_tiles = a.P;
@@ -729,6 +783,77 @@ extern "C" int dt_conv2d_winograd_affine(const dt_conv_desc* d, const float* src
   DT_REQUIRE(d->cout_split == 0 && d->accumulate == 0, "conv_winograd_affine: no split outputs / joins");
   dt_bn_bwd_fuse f{residual, nullptr, nullptr, scale, shift, nullptr};
   return dt_conv_wino_launch(d, src0, src1, u, out, nullptr, nullptr, nullptr, nullptr, &f, (hipStream_t)stream, true);
+}
+
+// Data gradient of a decoder conv1 — y = conv3x3(cat(nearest_upsample_x2(x), skip)) — with the up-sampling's backward in
+// the epilogue: `d` = the stride-1 data-gradient descriptor (C0 = the convolution's output channels, Cout = x's channels +
+// skip's, cout_split = x's channels, multiples of 64), u = dt_winograd_weights of the flipped / transposed weights.
+// gx [B, Hin/2, Win/2, cout_split] receives the 2x2-summed gradient of x, red the BatchNorm-backward sums of the layer that
+// produced x (fuse: its raw output at gx's resolution + mean / invstd / act_scale / act_shift), dskip [B, Hin, Win,
+// Cout - cout_split] the skip's gradient.  Two launches over disjoint channel blocks (EPI 6 / EPI 0); replaces
+// dt_conv2d_winograd (split outputs) + dt_upsample2x_bwd_bn.  P = dt_conv2d_winograd_upsampled_dgrad_rows(d).
+static int wn_updgrad_ok(const dt_conv_desc* d) {
+  static const int on = [] {
+    const char* e = getenv("DT_FP32_WINO_UPSAMPLE_BWD");
+    return (e == nullptr || e[0] != '0') ? 1 : 0;
+  }();
+  return on && dt_conv2d_winograd_supported(d) && d->mode0 == 0 && d->C1 == 0 && d->accumulate == 0 && d->cout_split > 0 &&
+         (d->cout_split % 64) == 0 && ((d->Hin | d->Win) & 1) == 0 && !wn_pack(d) && (32 % (d->cout_split / 64)) == 0;
+}
+
+extern "C" int dt_conv2d_winograd_upsampled_dgrad_supported(const dt_conv_desc* d) { return d != nullptr && wn_updgrad_ok(d); }
+
+extern "C" int dt_conv2d_winograd_upsampled_dgrad_rows(const dt_conv_desc* d) {
+  if (d == nullptr || !wn_updgrad_ok(d)) return 0;
+  const long total = (long)d->B * dt_cdiv(d->Ho, 16) * dt_cdiv(d->Wo, 16) * (d->cout_split / 64);
+  return (int)(total < WN_MAX_WGS ? total : WN_MAX_WGS);
+}
+
+extern "C" int dt_conv2d_winograd_upsampled_dgrad(const dt_conv_desc* d, const float* dy, const float* u, float* gx,
+                                                  float* dskip, float* red, const dt_bn_bwd_fuse* fuse, void* stream) {
+  DT_REQUIRE(d && dy && u && gx && red && fuse && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale &&
+                 fuse->act_shift && fuse->act == nullptr, "conv_winograd_upsampled_dgrad: null pointer / stored activation");
+  DT_REQUIRE(wn_updgrad_ok(d), "conv_winograd_upsampled_dgrad: layer shape not supported");
+  DT_REQUIRE(d->cout_split == d->Cout || dskip, "conv_winograd_upsampled_dgrad: dskip missing");
+  WinoArgs a;
+  a.bnb = *fuse;
+  a.src0 = dy; a.src1 = nullptr; a.u = u; a.in_scale = nullptr; a.in_shift = nullptr;
+  a.out0 = gx; a.out1 = dskip; a.stats = red;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.C0 = d->C0; a.C1 = 0; a.mode0 = 0;
+  a.Cout = d->Cout; a.cout_split = d->cout_split; a.accumulate = 0;
+  a.tiles_x = dt_cdiv(d->Wo, 16);
+  a.tiles_y = dt_cdiv(d->Ho, 16);
+  a.pack = 0;
+  a.nchunks = d->C0 / 8;
+  const size_t b0 = (size_t)d->B * d->Hin * d->Win * d->C0 * 4;
+  const size_t opx = (size_t)d->B * d->Ho * d->Wo * 4;
+  DT_REQUIRE(b0 < 0x80000000ull && opx * (d->Cout - d->cout_split) < 0x80000000ull,
+             "conv_winograd_upsampled_dgrad: an operand of 2 GiB or more");
+  a.bytes0 = (unsigned)b0; a.bytes1 = 0;
+  a.obytes0 = (unsigned)(opx / 4 * d->cout_split);       // (half resolution; the EPI 6 epilogue builds its own descriptors)
+  a.obytes1 = (unsigned)(opx * (d->Cout - d->cout_split));
+  a.ubytes = (unsigned)((size_t)16 * d->C0 * d->Cout * 4);
+  const int sp_tiles = d->B * a.tiles_x * a.tiles_y;
+  hipStream_t st = (hipStream_t)stream;
+  // launch A: the up-sampled part (channel blocks 0 .. cout_split / 64): 2x2 sums + BatchNorm-backward sums
+  a.nt0 = 0; a.n_tiles = d->cout_split / 64; a.stat_ld = d->cout_split; a.pstats = 1;
+  a.P = dt_conv2d_winograd_upsampled_dgrad_rows(d);
+  int total = sp_tiles * a.n_tiles;
+  hipLaunchKernelGGL((conv3x3_wino_kernel<false, 6, false>), dim3((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)),
+                     dim3(256), 0, st, a, total);
+  DT_LAUNCH_CHECK();
+  // launch B: the skip's channel blocks, plain store into dskip
+  if (d->Cout > d->cout_split) {
+    a.bnb = dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    a.stats = nullptr; a.pstats = 0; a.stat_ld = d->Cout;
+    a.nt0 = d->cout_split / 64; a.n_tiles = (d->Cout - d->cout_split) / 64;
+    a.obytes0 = 0;
+    total = sp_tiles * a.n_tiles;
+    hipLaunchKernelGGL((conv3x3_wino_kernel<false, 0, false>), dim3((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)),
+                       dim3(256), 0, st, a, total);
+    DT_LAUNCH_CHECK();
+  }
+  return DT_OK;
 }
 
 // data gradient with the BatchNorm-backward sums of the layer the gradient belongs to fused into the epilogue: the

@@ -1783,6 +1783,33 @@ class UNetEngine:
                 del dy1
                 S[f"D{i}"] = None
                 continue
+            if d["skip"] is not None and i >= 1 and self._fuse_bn and self.winograd:
+                # decoder blocks 1-3: the Winograd data gradient with the up-sampling's backward (2x2 sums) and the
+                # BatchNorm-backward sums of the block below in its epilogue; the skip's gradient from a second launch
+                c1 = blk.conv1
+                ddesc = self._desc(B, Hh, Ww, c1.cout, 0, 0, Hh, Ww, c1.cin, c1.k, 1, c1.k - 1 - c1.pad, cx, 0)
+                ud = self._u(c1, dgrad=True)
+                if ud is not None and lib.dt_conv2d_winograd_upsampled_dgrad_supported(C.byref(ddesc)):
+                    pb = sp.decoder[i - 1].conv2
+                    y2p = S[f"D{i - 1}"]["y2"]
+                    P = lib.dt_conv2d_winograd_upsampled_dgrad_rows(C.byref(ddesc))
+                    red = self._buf("bn_red_up", lib.dt_bn_stats_floats(P, cx), device=dev)
+                    psc, psh = self._ss(pb, bnws)
+                    nbq = sp.n_bn_channels
+                    fuse = _lib.BnBwdFuse(_p(y2p), _p(bnws[pb.bn_off: pb.bn_off + cx]),
+                                          _p(bnws[nbq + pb.bn_off: nbq + pb.bn_off + cx]), _p(psc), _p(psh))
+                    dskip = torch.empty_like(d["skip"])
+                    g = torch.empty_like(d["x"])
+                    ev = self._pb()
+                    _lib.check(lib.dt_conv2d_winograd_upsampled_dgrad(C.byref(ddesc), _p(dy1), _p(ud), _p(g), _p(dskip), _p(red),
+                                                                      C.byref(fuse), st), "dt_conv2d_winograd_upsampled_dgrad")
+                    self._pe(ev, self._wino_kernel_name(False, 6), 2.0 * 9 * c1.cin * c1.cout * Hh * Ww * B,
+                             4.0 * B * Hh * Ww * (c1.cout + (c1.cin - cx)) + 4.0 * B * (Hh // 2) * (Ww // 2) * cx * 2)
+                    skip_grads[3 - i] = dskip
+                    g_red = (red, P)
+                    del dy1
+                    S[f"D{i}"] = None
+                    continue
             dup = torch.empty((B, Hh, Ww, cx), dtype=torch.float32, device=dev)
             if d["skip"] is not None:
                 dskip = torch.empty_like(d["skip"])

@@ -244,6 +244,18 @@ int dt_conv2d_bn_bwd(const dt_conv_desc* desc, const float* src0, const float* w
 /* Winograd form of dt_conv2d_bn_bwd: same arguments, u = dt_winograd_weights of the flipped / transposed weights. */
 int dt_conv2d_winograd_bn_bwd(const dt_conv_desc* d, const float* src0, const float* u, float* out0, float* red,
                               const dt_bn_bwd_fuse* fuse, void* stream);
+/* Data gradient of a decoder conv1 — y = conv3x3(cat(nearest_upsample_x2(x), skip)) — with the up-sampling's backward in
+ * the Winograd epilogue (the 2x2 outputs of a Winograd tile are one source pixel's four gradients): `desc` = the stride-1
+ * data-gradient descriptor (C0 = the convolution's output channels, Cout = channels of x + skip, cout_split = channels of
+ * x; multiples of 64), u = dt_winograd_weights of the flipped / transposed weights.  gx [B, Hin/2, Win/2, cout_split] =
+ * gradient of x (2x2-summed, never stored at full resolution), red [2][P][cout_split] = BatchNorm-backward sums of the
+ * layer that produced x (fuse: its raw output at gx's resolution, mean, invstd, act_scale, act_shift), dskip [B, Hin,
+ * Win, Cout - cout_split] = gradient of the skip.  Replaces dt_conv2d_winograd (split outputs) + dt_upsample2x_bwd_bn
+ * (reference: autograd of torch.cat + F.interpolate(nearest, x2) + Conv2d in smp's DecoderBlock.forward). */
+int dt_conv2d_winograd_upsampled_dgrad_supported(const dt_conv_desc* desc);
+int dt_conv2d_winograd_upsampled_dgrad_rows(const dt_conv_desc* desc);
+int dt_conv2d_winograd_upsampled_dgrad(const dt_conv_desc* desc, const float* dy, const float* u, float* gx, float* dskip,
+                                       float* red, const dt_bn_bwd_fuse* fuse, void* stream);
 
 /* ------------------------------------------------------------------ segmentation head (K11,K12,K19) */
 /* logits[B,K,H,W] (NCHW) = conv3x3(x[B,H,W,Cin], w[K][3][3][Cin]) + bias; optional uint8/int64 argmax

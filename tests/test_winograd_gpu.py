@@ -287,3 +287,46 @@ def test_fused_inference_forward_is_bit_identical_to_the_unfused_one():
         cb = m.predict_classes(x, dtype="uint8").clone()
         eng._fuse_eval_opt = True
     assert torch.equal(a, b) and torch.equal(ca, cb)
+
+
+@pytest.mark.parametrize("B,H,W,Cy,cx,sk", [(2, 32, 48, 64, 128, 64), (1, 36, 20, 32, 64, 64), (3, 18, 34, 64, 64, 0),
+                                           (2, 16, 16, 128, 256, 128)])
+def test_winograd_data_gradient_with_fused_upsample_backward(B, H, W, Cy, cx, sk):
+    """dt_conv2d_winograd_upsampled_dgrad (epilogue form 6 + a plain launch for the skip's channels) against the chain it
+    replaces — dt_conv2d_winograd with split outputs, then dt_upsample2x_bwd_bn: the 2x2-summed gradient and the skip's
+    gradient bit-identical (same output transform, same (a + b) + (c + d) order), the BatchNorm-backward sums equal up to the
+    grouping of the partial rows; ragged maps (H, W not multiples of 16), with and without a skip"""
+    import ctypes as C
+    from deadtrees_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 7 + H + cx)
+    st = torch.cuda.current_stream().cuda_stream
+    dy = torch.randn((B, H, W, Cy), generator=g).to(DEV)
+    wt = torch.randn((3, 3, cx + sk, Cy), generator=g) * 0.05            # forward HWIO: (cx + sk) -> Cy
+    wd = ops.weight_flip_transpose(wt.to(DEV))                            # data-gradient image: Cy -> (cx + sk)
+    u = ops.winograd_weights(wd)
+    yl = torch.randn((B, H // 2, W // 2, cx), generator=g).to(DEV)
+    mu, istd = (0.1 * torch.randn(cx, generator=g)).to(DEV), (1 + 0.2 * torch.rand(cx, generator=g)).to(DEV)
+    sc, sh = (1 + 0.3 * torch.randn(cx, generator=g)).to(DEV), (0.2 * torch.randn(cx, generator=g)).to(DEV)
+    # the chain
+    dup, dskip_ref, _ = ops.conv2d_winograd(dy, u, split=cx if sk else 0)
+    g_ref, red_ref = ops.upsample2x_bwd_bn(dup, yl, mu, istd, sc, sh)
+    # one call
+    d = _lib.ConvDesc(B, H, W, Cy, 0, 0, H, W, cx + sk, 3, 1, 1, cx, 0)
+    assert lib.dt_conv2d_winograd_upsampled_dgrad_supported(C.byref(d))
+    P = lib.dt_conv2d_winograd_upsampled_dgrad_rows(C.byref(d))
+    red = torch.empty(lib.dt_bn_stats_floats(P, cx), dtype=torch.float32, device=DEV)
+    gx = torch.empty((B, H // 2, W // 2, cx), dtype=torch.float32, device=DEV)
+    dskip = torch.empty((B, H, W, sk), dtype=torch.float32, device=DEV) if sk else None
+    fuse = _lib.BnBwdFuse(yl.data_ptr(), mu.data_ptr(), istd.data_ptr(), sc.data_ptr(), sh.data_ptr())
+    _lib.check(lib.dt_conv2d_winograd_upsampled_dgrad(C.byref(d), dy.data_ptr(), u.data_ptr(), gx.data_ptr(),
+                                                      dskip.data_ptr() if sk else None, red.data_ptr(), C.byref(fuse), st),
+               "dt_conv2d_winograd_upsampled_dgrad")
+    assert torch.equal(gx, g_ref)
+    if sk:
+        assert torch.equal(dskip, dskip_ref)
+    got = red[:2 * P * cx].view(2, P, cx).double().sum(1).cpu()
+    want = red_ref.double().sum(1).cpu()
+    tol = 1e-5 * float(want.abs().max())
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=tol)
