@@ -61,7 +61,7 @@ SIGNATURES = {
     "dt_conv2d_winograd_bn_bwd": (C.c_int, [_P, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
     "dt_conv2d_winograd_upsampled_dgrad_supported": (C.c_int, [_P]),
     "dt_conv2d_winograd_upsampled_dgrad_rows": (C.c_int, [_P]),
-    "dt_conv2d_winograd_upsampled_dgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), c_f]),
+    "dt_conv2d_winograd_upsampled_dgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, C.POINTER(BnBwdFuse), C.c_int, c_f]),
     "dt_conv2d_wgrad_workspace": (SZ, [_P]),
     "dt_conv2d_wgrad": (C.c_int, [_P, c_f, c_f, c_f, c_f, c_f, SZ, c_f, c_f, c_f]),
     "dt_conv2d_wgrad_winograd_supported": (C.c_int, [_P]),

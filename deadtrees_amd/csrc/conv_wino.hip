@@ -810,7 +810,8 @@ extern "C" int dt_conv2d_winograd_upsampled_dgrad_rows(const dt_conv_desc* d) {
 }
 
 extern "C" int dt_conv2d_winograd_upsampled_dgrad(const dt_conv_desc* d, const float* dy, const float* u, float* gx,
-                                                  float* dskip, float* red, const dt_bn_bwd_fuse* fuse, void* stream) {
+                                                  float* dskip, float* red, const dt_bn_bwd_fuse* fuse, int launches,
+                                                  void* stream) {   // launches: 1 = the up-sampled part, 2 = the skip part, 3 = both
   DT_REQUIRE(d && dy && u && gx && red && fuse && fuse->y && fuse->mean && fuse->invstd && fuse->act_scale &&
                  fuse->act_shift && fuse->act == nullptr, "conv_winograd_upsampled_dgrad: null pointer / stored activation");
   DT_REQUIRE(wn_updgrad_ok(d), "conv_winograd_upsampled_dgrad: layer shape not supported");
@@ -839,11 +840,13 @@ extern "C" int dt_conv2d_winograd_upsampled_dgrad(const dt_conv_desc* d, const f
   a.nt0 = 0; a.n_tiles = d->cout_split / 64; a.stat_ld = d->cout_split; a.pstats = 1;
   a.P = dt_conv2d_winograd_upsampled_dgrad_rows(d);
   int total = sp_tiles * a.n_tiles;
-  hipLaunchKernelGGL((conv3x3_wino_kernel<false, 6, false>), dim3((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)),
-                     dim3(256), 0, st, a, total);
-  DT_LAUNCH_CHECK();
+  if (launches & 1) {
+    hipLaunchKernelGGL((conv3x3_wino_kernel<false, 6, false>), dim3((unsigned)(total < WN_MAX_WGS ? total : WN_MAX_WGS)),
+                       dim3(256), 0, st, a, total);
+    DT_LAUNCH_CHECK();
+  }
   // launch B: the skip's channel blocks, plain store into dskip
-  if (d->Cout > d->cout_split) {
+  if ((launches & 2) && d->Cout > d->cout_split) {
     a.bnb = dt_bn_bwd_fuse{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     a.stats = nullptr; a.pstats = 0; a.stat_ld = d->Cout;
     a.nt0 = d->cout_split / 64; a.n_tiles = (d->Cout - d->cout_split) / 64;

@@ -321,7 +321,7 @@ def test_winograd_data_gradient_with_fused_upsample_backward(B, H, W, Cy, cx, sk
     dskip = torch.empty((B, H, W, sk), dtype=torch.float32, device=DEV) if sk else None
     fuse = _lib.BnBwdFuse(yl.data_ptr(), mu.data_ptr(), istd.data_ptr(), sc.data_ptr(), sh.data_ptr())
     _lib.check(lib.dt_conv2d_winograd_upsampled_dgrad(C.byref(d), dy.data_ptr(), u.data_ptr(), gx.data_ptr(),
-                                                      dskip.data_ptr() if sk else None, red.data_ptr(), C.byref(fuse), st),
+                                                      dskip.data_ptr() if sk else None, red.data_ptr(), C.byref(fuse), 3, st),
                "dt_conv2d_winograd_upsampled_dgrad")
     assert torch.equal(gx, g_ref)
     if sk:
