@@ -429,6 +429,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
       const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, lbytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsyl = __builtin_amdgcn_make_buffer_rsrc((void*)a.bnb.y, 0, lbytes, 0x00020000);
       const int ysrc = (oy0 >> 1) + 4 * wave_m, xsrc = (ox0 >> 1) + 4 * kh;
+      // the 16 raw outputs y of the tile's source pixels are requested up front: the first quarter's output transform runs
+      // under their latency (loaded per quarter, the epilogue of the up-sampled half was slower than the plain half's)
+      float yall[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool ok = ysrc + (i >> 2) < Hs && xsrc + (i & 3) < Ws;
+        yall[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsyl, ok ? llane : WN_OOB,
+                                                                                 lbase + (i >> 2) * rowl4 + (i & 3) * ldl4, 0));
+      }
 #pragma unroll
       for (int qr = 0; qr < 4; ++qr) {
         unsigned off[4];
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_kernel(const WinoArgs a, 
           const bool ok = ysrc + (i >> 2) < Hs && xsrc + (i & 3) < Ws;
           off[ii] = ok ? llane : WN_OOB;
           soff[ii] = lbase + (i >> 2) * rowl4 + (i & 3) * ldl4;
-          yv[ii] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsyl, off[ii], soff[ii], 0));
+          yv[ii] = yall[i];
         }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
