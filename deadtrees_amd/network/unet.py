@@ -1800,14 +1800,11 @@ class UNetEngine:
                                           _p(bnws[nbq + pb.bn_off: nbq + pb.bn_off + cx]), _p(psc), _p(psh))
                     dskip = torch.empty_like(d["skip"])
                     g = torch.empty_like(d["x"])
-                    # (its two launches separately when per-launch events are on: each under its own kernel's name)
-                    for part, epi, cpart in ((1, 6, cx), (2, 0, c1.cin - cx)) if self.profile is not None else ((3, 6, c1.cin),):
-                        ev = self._pb()
-                        _lib.check(lib.dt_conv2d_winograd_upsampled_dgrad(C.byref(ddesc), _p(dy1), _p(ud), _p(g), _p(dskip), _p(red),
-                                                                          C.byref(fuse), part, st),
-                                   "dt_conv2d_winograd_upsampled_dgrad")
-                        self._pe(ev, self._wino_kernel_name(False, epi), 2.0 * 9 * cpart * c1.cout * Hh * Ww * B,
-                                 4.0 * B * Hh * Ww * (c1.cout + (cpart if epi == 0 else 0.5 * cpart)))
+                    ev = self._pb()
+                    _lib.check(lib.dt_conv2d_winograd_upsampled_dgrad(C.byref(ddesc), _p(dy1), _p(ud), _p(g), _p(dskip), _p(red),
+                                                                      C.byref(fuse), 3, st), "dt_conv2d_winograd_upsampled_dgrad")
+                    self._pe(ev, self._wino_kernel_name(False, 6), 2.0 * 9 * c1.cin * c1.cout * Hh * Ww * B,
+                             4.0 * B * Hh * Ww * (c1.cout + (c1.cin - cx)) + 4.0 * B * (Hh // 2) * (Ww // 2) * cx * 2)
                     skip_grads[3 - i] = dskip
                     g_red = (red, P)
                     del dy1

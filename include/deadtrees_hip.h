@@ -255,7 +255,7 @@ int dt_conv2d_winograd_bn_bwd(const dt_conv_desc* d, const float* src0, const fl
 int dt_conv2d_winograd_upsampled_dgrad_supported(const dt_conv_desc* desc);
 int dt_conv2d_winograd_upsampled_dgrad_rows(const dt_conv_desc* desc);
 int dt_conv2d_winograd_upsampled_dgrad(const dt_conv_desc* desc, const float* dy, const float* u, float* gx, float* dskip,
-                                       float* red, const dt_bn_bwd_fuse* fuse, int launches /* 1: gx + red, 2: dskip, 3: both */,
+                                       float* red, const dt_bn_bwd_fuse* fuse, int launches /* reserved: pass 3 */,
                                        void* stream);
 
 /* ------------------------------------------------------------------ segmentation head (K11,K12,K19) */
